@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- EM iterations/sec (+ bootstraps/sec) of the MI355X EM engine.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line
+on rank 0.  For N>1 it is launched under torch.distributed.run, one rank per GPU.
+
+* workload  : BASELINE.json's metric configuration, "ONT direct-RNA-scale 10M reads x 200k
+              txps" (k-bar = 8 => ~80 M alignments), synthetic, seeded.
+* a "step"  : one EM loop iteration = E/M pass + (all-reduce) + rel-diff/swap/clear
+              (em.rs:181-207) over the whole store, which is resident in HBM before timing.
+* value     : iterations/sec of the whole job (strong scaling: the store is row-sharded over
+              the N GPUs, one RCCL all-reduce of the count vector per iteration).
+* roofline  : algorithmic bytes of one E/M pass / HIP-event-timed average duration of the
+              E/M kernel, against the 8 TB/s HBM peak.
+* cpu_baseline : the C restatement of em_par (oracle/, all host cores) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"])
+    ap.add_argument("--bootstraps", type=int, default=2, help="bootstrap replicates to time (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    "c3": dict(n_reads=10_000_000, n_txps=200_000, kbar=8.0,
+               name="synthetic 10M reads x 200k txps, avg 8 aln/read (BASELINE configs[2]/[3])"),
+    "c2": dict(n_reads=1_000_000, n_txps=60_000, kbar=8.0,
+               name="synthetic 1M reads x 60k txps, avg 8 aln/read (BASELINE configs[1])"),
+    "tiny": dict(n_reads=100_000, n_txps=8_000, kbar=8.0, name="tiny plumbing workload"),
+}
+
+
+def make_shard(cfg, rank, world):
+    """Rows [r0, r1) of the seeded store; chunk c is a pure function of (seed, c)."""
+    from oarfish_amd import synth
+    R = cfg["n_reads"]
+    r0, r1 = rank * R // world, (rank + 1) * R // world
+    if world == 1:
+        st = synth.make_store(R, cfg["n_txps"], cfg["kbar"], threads=min(32, os.cpu_count() or 8))
+        return st.row_ptr, st.tid, st.as_prob, r0, r1
+    # generate only the covering chunks, then slice
+    c0, c1 = r0 // synth.CHUNK, (r1 - 1) // synth.CHUNK
+    rng0 = np.random.default_rng([synth.BASE_SEED, 0xA11CE])
+    a = rng0.lognormal(0.0, 2.0, size=cfg["n_txps"])
+    a /= a.sum()
+    cdf = np.cumsum(a)
+    cdf /= cdf[-1]
+    g_start, g_size, gene_of = synth._genes(cfg["n_txps"], rng0)
+    lens, tids, ps = [], [], []
+    for c in range(c0, c1 + 1):
+        n = min(synth.CHUNK, R - c * synth.CHUNK)
+        l, t, p, _ = synth._chunk(c, n, synth.BASE_SEED, cfg["n_txps"], cfg["kbar"], cdf, g_start,
+                                  g_size, gene_of, False)
+        lens.append(l)
+        tids.append(t)
+        ps.append(p)
+    lens = np.concatenate(lens)
+    tid = np.concatenate(tids)
+    p = np.concatenate(ps)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    lo, hi = r0 - c0 * synth.CHUNK, r1 - c0 * synth.CHUNK
+    a0, a1 = int(off[lo]), int(off[hi])
+    return (off[lo:hi + 1] - off[lo]).astype(np.uint64), tid[a0:a1], p[a0:a1], r0, r1
+
+
+def cpu_baseline(row_ptr, tid, p, n_txps, seconds):
+    """The oracle's em_par restatement (rayon + AtomicF64 analogue) on all host cores, on a
+    bounded number of iterations of the same store."""
+    from oracle import c_oracle
+    cores = os.cpu_count() or 1
+    s = c_oracle.Store(row_ptr, tid, p, None, n_txps)
+    t = time.perf_counter()
+    c_oracle.em_par(s, max_iter=2, conv_thresh=0.0, nthreads=cores)  # 3 passes
+    per_pass = (time.perf_counter() - t) / 3
+    iters = int(max(3, min(200, seconds / max(per_pass, 1e-6))))
+    t = time.perf_counter()
+    c_oracle.em_par(s, max_iter=iters, conv_thresh=0.0, nthreads=cores)
+    dt = time.perf_counter() - t
+    par = iters / dt  # iters loop iterations (+1 final pass, counted against us)
+    # serial em::em semantics, 1 core, fewer iterations
+    it1 = max(2, iters // max(cores // 2, 1))
+    t = time.perf_counter()
+    c_oracle.do_em(s, max_iter=it1, conv_thresh=0.0)
+    ser = it1 / (time.perf_counter() - t)
+    return dict(value=par, unit="EM iterations/s", cores=cores, kind="port",
+                sample=f"{iters} iterations of the em_par restatement (oracle/oem_oracle.c, OpenMP "
+                       f"row-parallel + CAS f64 add, 8 B/nnz SoA) over the full store, {cores} threads",
+                serial_1core_value=ser)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: oarfish_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oarfish_amd import _lib
+    from oarfish_amd import build as _b
+    if rank == 0:
+        _b.build()
+    if world > 1:
+        dist.barrier()
+    from oarfish_amd.types import DeviceStore
+    from oarfish_amd import dist as odist
+
+    cfg = WORKLOADS[args.workload]
+    t_gen = time.perf_counter()
+    row_ptr, tid, p, r0, r1 = make_shard(cfg, rank, world)
+    t_gen = time.perf_counter() - t_gen
+    t_up = time.perf_counter()
+    store = DeviceStore(row_ptr, tid, p, None, cfg["n_txps"], device=local_rank)
+    t_up = time.perf_counter() - t_up
+    comm = None
+    if world > 1:
+        comm = odist.create_comm(rank, world, local_rank)
+        store.attach_comm(comm.handle, cfg["n_reads"], r0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup, then exactly K timed iterations
+    if args.warmup > 0:
+        store.time_em_iters(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    dev_ms = store.time_em_iters(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    it_per_s = args.steps / elapsed
+
+    # dominant kernel: HIP-event-timed average launch duration of the E/M pass
+    hbm_bytes, alg_bytes = store.bytes()
+    k_ms = store.time_m_step(50)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None, kernel="k_em_pass",
+                    kernel_avg_ms=k_ms, algorithmic_bytes_per_launch=alg_bytes)
+
+    # bootstraps/sec (each = one resampled EM to convergence, em.rs:273-290)
+    boots = None
+    if args.bootstraps > 0:
+        sync()
+        tb = time.perf_counter()
+        _out, infos = store.bootstrap(args.bootstraps, seed=1, max_iter=1000, conv_thresh=1e-3)
+        sync()
+        tb = time.perf_counter() - tb
+        boots = dict(value=args.bootstraps / tb, unit="bootstraps/s", n=args.bootstraps,
+                     mean_passes=float(np.mean([i.n_passes for i in infos])))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(row_ptr, tid, p, cfg["n_txps"], args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "EM iterations/sec",
+            "value": it_per_s,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": cfg["name"], "n_reads": cfg["n_reads"], "n_txps": cfg["n_txps"],
+                       "nnz_local": int(len(tid)), "parallelism": f"row-shard x{world}",
+                       "gen_s": round(t_gen, 2), "upload_s": round(t_up, 2),
+                       "device_ms_per_step": dev_ms / args.steps},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "bootstraps": boots,
+        }
+        print(json.dumps(out))
+    store.close()
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+/*
+ * oarfish_em.h -- C ABI of the MI355X-native EM quantification engine.
+ *
+ * This is the drop-in boundary for oarfish's abundance-estimation hot path
+ * (COMBINE-lab/oarfish v0.10.3, src/em.rs + src/bootstrap.rs).  The reference
+ * has no FFI layer; the seam it would bind is three Rust functions
+ *     em::em      (src/em.rs:262)   -> oem_em_run(..., min_iter_gate = 50)
+ *     em::em_par  (src/em.rs:320)   -> oem_em_run(..., min_iter_gate = 1)
+ *     em::bootstrap (src/em.rs:292) -> oem_bootstrap
+ * over an `EMInfo` (src/util/oarfish_types.rs:408-428), whose `eq_map`
+ * (`InMemoryAlignmentStore`, :548-558) becomes an `oem_store` handle that keeps
+ * the sparse read x transcript conditional-probability matrix resident in HBM.
+ * INTEGRATION.md shows the Rust `extern "C"` block + shim a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host buffers are caller-owned and are
+ *     never retained after the call returns (the store is copied to HBM);
+ *   - every entry point returns an `oem_status` (0 = OK) and never aborts or
+ *     throws across the boundary (the reference's EM is infallible and built
+ *     with panic=abort, Cargo.toml:118; a GPU library cannot be);
+ *   - `oem_last_error()` gives the thread-local message of the last failure;
+ *   - calls on distinct handles are thread-safe (single_cell.rs:96-150 calls
+ *     em::em concurrently from N workers); calls on one handle are serialised.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with OEM_ERR_NO_DEVICE.
+ */
+#ifndef OARFISH_EM_H
+#define OARFISH_EM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OEM_ABI_VERSION 1
+
+typedef enum {
+    OEM_OK = 0,
+    OEM_ERR_ARG = 1,       /* NULL / inconsistent argument (bad row_ptr, tid >= n_txps ...) */
+    OEM_ERR_OOM = 2,       /* host or device allocation failed */
+    OEM_ERR_HIP = 3,       /* HIP runtime error */
+    OEM_ERR_RCCL = 4,      /* RCCL error / librccl not loadable */
+    OEM_ERR_NO_DEVICE = 5, /* no usable HIP device */
+    OEM_ERR_STATE = 6      /* handle used in a state that does not allow the call */
+} oem_status;
+
+/* src/util/constants.rs:1-2 */
+#define OEM_MIN_READ_THRESH 1e-5
+#define OEM_EM_DENOM_THRESH 1e-30
+
+/* Opaque handles. */
+typedef struct oem_store oem_store; /* InMemoryAlignmentStore resident on one GPU (one row shard) */
+typedef struct oem_comm oem_comm;   /* RCCL communicator over the row shards of one node */
+
+/* What do_em / em_par leave behind besides the counts. */
+typedef struct {
+    uint32_t niter;     /* value of `niter` at loop exit (em.rs:170,218 / :354,405) */
+    uint32_t n_passes;  /* E/M passes executed, including the final one (em.rs:245 / :433) */
+    uint32_t converged; /* 1 if the loop left through `break` (em.rs:212-214 / :399-401) */
+    uint32_t reserved;
+    double rel_diff;    /* rel_diff of the last loop pass (em.rs:194-201), as logged at :219-233 */
+} oem_run_info;
+
+/* Layout / tuning knobs of a store (all optional; zero = default). */
+typedef struct {
+    uint32_t reorder_rows; /* 0 = default (locality reorder on), 1 = keep caller order, 2 = force reorder */
+    uint32_t reserved[7];
+} oem_store_opts;
+
+/* --------------------------------------------------------------------- */
+/* library                                                                */
+/* --------------------------------------------------------------------- */
+int oem_abi_version(void);
+const char *oem_last_error(void);
+int oem_device_count(int *out_count);
+
+/* --------------------------------------------------------------------- */
+/* alignment store                                                        */
+/* --------------------------------------------------------------------- */
+
+/* Replaces InMemoryAlignmentStore as em.rs reads it (oarfish_types.rs:548-558
+ * via iter(), :651-656): row_ptr == boundaries (n_reads+1 entries, row_ptr[0]==0,
+ * strictly increasing: the reference never stores an empty read, :724,735-737;
+ * empty rows are tolerated and contribute nothing), tid == alignments[].ref_id,
+ * as_prob == as_probabilities (f32, :552), cov_prob == coverage_probabilities
+ * (f64) or NULL when filter_opts.model_coverage is false (em.rs:108).
+ * `device` is the HIP device ordinal.  The arrays are copied to HBM, laid out
+ * for the E/M kernels, and may be freed by the caller on return. */
+int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
+                     const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
+                     int device, const oem_store_opts *opts, oem_store **out);
+void oem_store_destroy(oem_store *store);
+
+/* store.len() / num_aligned_reads() (oarfish_types.rs:562-564,746-748),
+ * total_len() (:741-743), txp_info.len(). */
+int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uint32_t *n_txps);
+
+/* Bytes of HBM the store occupies and the algorithmic bytes of one E/M pass
+ * (nnz*(4+4|8) + (R+1)*4 + 2*T*8). */
+int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass);
+
+/* --------------------------------------------------------------------- */
+/* EM                                                                     */
+/* --------------------------------------------------------------------- */
+
+/* One E/M pass (em.rs:87-133 m_step): out_counts[t] = sum over reads i of
+ * row_w[i] * theta[t]*w_it / sum_j theta[t_j]*w_ij, reads with denominator
+ * <= 1e-30 dropped (em.rs:115).  row_w == NULL means all ones.  theta and
+ * out_counts are host arrays of n_txps f64.  For step-level parity tests and
+ * external loop drivers; the fused drivers below never leave the device. */
+int oem_m_step(oem_store *store, const double *theta, const uint32_t *row_w, double *out_counts);
+
+/* The EM driver (em.rs:144-255 do_em / :320-447 em_par).
+ *   init_abundances : n_txps f64 or NULL => uniform n_reads/n_txps (em.rs:160-167)
+ *   max_iter        : EMInfo.max_iter (prog_opts.rs:532, default 1000)
+ *   conv_thresh     : EMInfo.convergence_thresh (prog_opts.rs:536, default 1e-3)
+ *   min_iter_gate   : 50 reproduces em::em (em.rs:212), 1 reproduces em::em_par (em.rs:399)
+ *   out_counts      : n_txps f64, un-normalised expected read counts (em.rs:254)
+ *   info            : optional
+ * The stopping iteration is the reference's: the loop state is frozen on the
+ * device at the first pass that satisfies the gate. */
+int oem_em_run(oem_store *store, const double *init_abundances, uint32_t max_iter,
+               double conv_thresh, uint32_t min_iter_gate, double *out_counts,
+               oem_run_info *info);
+
+/* --------------------------------------------------------------------- */
+/* bootstrap                                                              */
+/* --------------------------------------------------------------------- */
+
+/* Device-side draw of one bootstrap resample in multiplicity form: the
+ * Multinomial(n_reads; 1/n_reads ...) count vector of bootstrap.rs:7-16
+ * (n draws from Uniform[0,n) with replacement; sorting is immaterial once
+ * expressed as counts).  Counter-based (Philox4x32-10) stream keyed by
+ * (seed, replica).  out_row_w: n_reads u32 on the host. */
+int oem_bootstrap_weights(oem_store *store, uint64_t seed, uint32_t replica, uint32_t *out_row_w);
+
+/* em::bootstrap (em.rs:292-314): n_boot resampled EMs, each do_bootstrap
+ * (em.rs:273-290) = do_em over random_sampling_iter with gate niter>50.
+ *   row_w_all : optional n_boot x n_reads u32 (row-major) to inject the
+ *               resamples (parity tests); NULL => drawn on the device as
+ *               oem_bootstrap_weights(seed, b).
+ *   out       : n_boot x n_txps f64, row-major (replicate-major, as the
+ *               Vec<Vec<f64>> of em.rs:292 / columns bootstrap.{i} of bulk.rs:181-193)
+ *   infos     : optional, n_boot entries. */
+int oem_bootstrap(oem_store *store, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all,
+                  const double *init_abundances, uint32_t max_iter, double conv_thresh,
+                  double *out, oem_run_info *infos);
+
+/* --------------------------------------------------------------------- */
+/* single-cell batch                                                      */
+/* --------------------------------------------------------------------- */
+
+/* The per-cell contract of single_cell.rs:139-160: every cell is an
+ * independent em::em(&emi, 1) with init_abundances None, gate 50, over its
+ * own reads.  Cells are given as one concatenated CSR (arrays as in
+ * oem_store_create) plus cell_row_off[n_cells+1] (read offsets per cell);
+ * out is n_cells x n_txps f64 row-major (the caller keeps entries > 0 as
+ * (col u32, val f32) triplets, single_cell.rs:155-160). */
+int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, const uint64_t *row_ptr,
+                     const uint32_t *tid, const float *as_prob, const double *cov_prob,
+                     uint64_t n_reads, uint64_t nnz, uint32_t n_txps, int device,
+                     uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos);
+
+/* --------------------------------------------------------------------- */
+/* multi-GPU (row shards + one RCCL all-reduce of the count vector / pass) */
+/* --------------------------------------------------------------------- */
+
+#define OEM_UNIQUE_ID_BYTES 128
+/* Rank 0 obtains an id and hands it to the other ranks through whatever the
+ * host uses (torch.distributed broadcast, MPI, a file ...). */
+int oem_comm_unique_id(void *out_id /* OEM_UNIQUE_ID_BYTES */);
+int oem_comm_create(const void *unique_id, int rank, int n_ranks, int device, oem_comm **out);
+void oem_comm_destroy(oem_comm *comm);
+
+/* Declare `store` to be rank-local row shard of a store with
+ * `global_n_reads` reads in total (needed for the uniform init, em.rs:154,165).
+ * After this, oem_em_run / oem_bootstrap on the shard are collective calls:
+ * every rank must make them with the same arguments; each pass all-reduces
+ * (sum, f64) the n_txps partial counts over `comm`, after which all ranks take
+ * the identical convergence decision. */
+int oem_store_attach_comm(oem_store *store, oem_comm *comm, uint64_t global_n_reads,
+                          uint64_t global_row_offset);
+
+/* --------------------------------------------------------------------- */
+/* measurement                                                            */
+/* --------------------------------------------------------------------- */
+
+/* Launch the E/M kernel `n_launches` times back to back on the store's
+ * stream, bracketed by HIP events on that stream; returns the average
+ * launch duration in milliseconds (bench.py's roofline.achieved). */
+int oem_time_m_step(oem_store *store, uint32_t n_launches, float *out_avg_ms);
+
+/* Run exactly `n_iters` loop iterations (E/M pass + rel-diff + swap/clear,
+ * em.rs:181-207) from the uniform init with no convergence exit, timed with
+ * HIP events on the store's stream; out_ms = total milliseconds. */
+int oem_time_em_iters(oem_store *store, uint32_t n_iters, float *out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OARFISH_EM_H */

@@ -1,0 +1,112 @@
+"""ctypes loader of liboarfish_em.so (the C ABI of include/oarfish_em.h).
+
+There is no Python or CPU fallback: if the shared library is missing the import
+of the product path fails loudly, and every compute entry point of the library
+returns OEM_ERR_NO_DEVICE when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboarfish_em.so")
+
+OEM_OK = 0
+OEM_ERR_ARG = 1
+OEM_ERR_OOM = 2
+OEM_ERR_HIP = 3
+OEM_ERR_RCCL = 4
+OEM_ERR_NO_DEVICE = 5
+OEM_ERR_STATE = 6
+OEM_UNIQUE_ID_BYTES = 128
+
+# every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "oem_abi_version", "oem_last_error", "oem_device_count",
+    "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes",
+    "oem_m_step", "oem_em_run",
+    "oem_bootstrap_weights", "oem_bootstrap",
+    "oem_em_run_cells",
+    "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_store_attach_comm",
+    "oem_time_m_step", "oem_time_em_iters",
+]
+
+
+class OemError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"oarfish_em error {code}: {msg}")
+        self.code = code
+
+
+class RunInfoC(C.Structure):
+    _fields_ = [
+        ("niter", C.c_uint32),
+        ("n_passes", C.c_uint32),
+        ("converged", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("rel_diff", C.c_double),
+    ]
+
+
+class StoreOptsC(C.Structure):
+    _fields_ = [("reorder_rows", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m oarfish_amd.build` "
+            "(or __graft_entry__.build()).  oarfish_amd has no CPU fallback."
+        )
+    try:  # make sure the process has ONE HIP runtime / RCCL: torch's, if torch is around
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    L.oem_abi_version.restype = i32
+    L.oem_last_error.restype = C.c_char_p
+    L.oem_device_count.argtypes = [C.POINTER(i32)]
+    L.oem_store_create.argtypes = [vp, vp, vp, vp, u64, u64, u32, i32, vp, C.POINTER(vp)]
+    L.oem_store_destroy.argtypes = [vp]
+    L.oem_store_destroy.restype = None
+    L.oem_store_dims.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    L.oem_store_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.oem_m_step.argtypes = [vp, vp, vp, vp]
+    L.oem_em_run.argtypes = [vp, vp, u32, f64, u32, vp, C.POINTER(RunInfoC)]
+    L.oem_bootstrap_weights.argtypes = [vp, u64, u32, vp]
+    L.oem_bootstrap.argtypes = [vp, u32, u64, vp, vp, u32, f64, vp, vp]
+    L.oem_em_run_cells.argtypes = [vp, u32, vp, vp, vp, vp, u64, u64, u32, i32, u32, f64, vp, vp]
+    L.oem_comm_unique_id.argtypes = [vp]
+    L.oem_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.oem_comm_destroy.argtypes = [vp]
+    L.oem_comm_destroy.restype = None
+    L.oem_store_attach_comm.argtypes = [vp, vp, u64, u64]
+    L.oem_time_m_step.argtypes = [vp, u32, C.POINTER(C.c_float)]
+    L.oem_time_em_iters.argtypes = [vp, u32, C.POINTER(C.c_float)]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("oem_abi_version",):
+            pass
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != OEM_OK:
+        msg = lib().oem_last_error()
+        raise OemError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().oem_device_count(C.byref(n)))
+    return int(n.value)

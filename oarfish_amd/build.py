@@ -1,0 +1,67 @@
+"""Builds liboarfish_em.so (the C-ABI library) in-tree with hipcc for gfx950.
+
+The library is plain HIP/C++: no torch types, no pybind.  hipcc cross-compiles
+gfx950 code objects without a GPU, so this runs in the CPU-only container too.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_PATH = os.path.join(HERE, "liboarfish_em.so")
+
+SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_comm.cpp"]
+HEADERS = ["oem_internal.h", os.path.join(INCLUDE, "oarfish_em.h")]
+
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-munsafe-fp-atomics",  # hardware global_atomic_add_f64 / ds_add_f64, no CAS loops
+    "-ffp-contract=off",    # keep (theta*w)*inv as written; parity is judged in f64
+    "-Wall",
+    "-Wno-unused-function",
+    "-Wno-unused-value",
+    "-Wno-unused-result",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build liboarfish_em.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
+        h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS
+    ] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH + ".tmp", "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

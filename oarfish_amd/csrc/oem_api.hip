@@ -1,0 +1,506 @@
+// oem_api.hip -- the C ABI of include/oarfish_em.h: store management and the
+// device-resident EM / bootstrap / per-cell drivers.
+//
+// Reference call sites this replaces (COMBINE-lab/oarfish v0.10.3):
+//   bulk.rs:155-159   em::em / em::em_par      -> oem_em_run
+//   bulk.rs:178-194   em::bootstrap            -> oem_bootstrap
+//   single_cell.rs:139-160  per-cell em::em    -> oem_em_run_cells
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "oem_internal.h"
+
+namespace oem {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char t_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int comm_rank(const Comm *c);
+int comm_size(const Comm *c);
+
+namespace {
+
+int ensure_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(OEM_ERR_NO_DEVICE,
+                    "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(OEM_ERR_ARG, "device ordinal %d out of range [0,%d)", device, n);
+    OEM_HIP(hipSetDevice(device));
+    return OEM_OK;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t n, uint64_t *acct)
+{
+    *p = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    OEM_HIP(hipMalloc((void **)p, bytes));
+    if (acct) *acct += bytes;
+    return OEM_OK;
+}
+
+int validate_csr(const uint64_t *row_ptr, const uint32_t *tid, uint64_t n_reads, uint64_t nnz,
+                 uint32_t n_txps)
+{
+    if (row_ptr[0] != 0) return fail(OEM_ERR_ARG, "row_ptr[0] must be 0 (oarfish_types.rs:645)");
+    for (uint64_t i = 0; i < n_reads; ++i)
+        if (row_ptr[i + 1] < row_ptr[i])
+            return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu",
+                        (unsigned long long)i);
+    if (row_ptr[n_reads] != nnz)
+        return fail(OEM_ERR_ARG, "row_ptr[n_reads]=%llu differs from nnz=%llu",
+                    (unsigned long long)row_ptr[n_reads], (unsigned long long)nnz);
+    for (uint64_t j = 0; j < nnz; ++j)
+        if (tid[j] >= n_txps)
+            return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u", (unsigned long long)j,
+                        tid[j], n_txps);
+    return OEM_OK;
+}
+
+struct RunArgs {
+    const double *init = nullptr; // host, n_txps, or NULL
+    const uint32_t *d_row_w = nullptr; // device multiplicities or NULL
+    uint64_t row_begin = 0, row_end = 0;
+    uint64_t total_reads = 0; // em.rs:154 total_weight
+    uint32_t max_iter = 1000;
+    double conv_thresh = 1e-3;
+    uint32_t min_iter_gate = 50;
+};
+
+// one loop iteration on the stream: E/M pass, (all-reduce), rel-diff/swap/clear
+int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
+{
+    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, s->d_state, a.d_row_w, a.row_begin, a.row_end));
+    if (s->comm && comm_size(s->comm) > 1)
+        OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, p.n_txps, s->stream));
+    OEM_TRY(launch_reldiff_swap_clear(s, s->theta, s->cnt, s->d_state, p));
+    return OEM_OK;
+}
+
+// em.rs:144-255 / :320-447 with the loop state on the device.  On return the
+// final counts are in s->cnt (device); *info filled from the device state.
+int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
+{
+    const uint32_t T = s->csr.n_txps;
+    EmParams p{T, a.max_iter, a.min_iter_gate, a.conv_thresh};
+
+    if (a.init) {
+        OEM_HIP(hipMemcpyAsync(s->theta, a.init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+    } else {
+        const double avg = (double)a.total_reads / (double)T; // em.rs:165
+        OEM_TRY(launch_fill(s, s->theta, avg, T));
+    }
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
+    std::memset(s->h_state, 0, sizeof(EmState));
+
+    // The stopping rule cannot fire before niter > gate, so the first look at
+    // the device state is due after gate+2 passes; afterwards every `kChunk`.
+    uint32_t launched = 0;
+    constexpr uint32_t kChunk = 16;
+    while (launched < a.max_iter) {
+        uint32_t chunk = launched == 0 ? a.min_iter_gate + 2 : kChunk;
+        if (chunk > a.max_iter - launched) chunk = a.max_iter - launched;
+        for (uint32_t k = 0; k < chunk; ++k) OEM_TRY(enqueue_iteration(s, a, p));
+        launched += chunk;
+        OEM_HIP(hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream));
+        OEM_HIP(hipStreamSynchronize(s->stream));
+        if (s->h_state->done) break;
+    }
+
+    OEM_TRY(launch_zero_small(s, s->theta, s->cnt, T));                                  // em.rs:238-242
+    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, a.d_row_w, a.row_begin, a.row_end)); // em.rs:245-252
+    if (s->comm && comm_size(s->comm) > 1)
+        OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
+    if (info) {
+        info->niter = s->h_state->niter;
+        info->n_passes = s->h_state->n_passes + 1;
+        info->converged = s->h_state->converged;
+        info->reserved = 0;
+        info->rel_diff = s->h_state->last_rel;
+    }
+    return OEM_OK;
+}
+
+int copy_counts_out(oem_store *s, double *out)
+{
+    const uint32_t T = s->csr.n_txps;
+    OEM_HIP(hipMemcpyAsync(s->h_pinned, s->cnt, sizeof(double) * T, hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    std::memcpy(out, s->h_pinned, sizeof(double) * T);
+    return OEM_OK;
+}
+
+int ensure_row_w(oem_store *s)
+{
+    if (!s->d_row_w) OEM_TRY(dev_alloc(&s->d_row_w, s->csr.n_reads, &s->hbm_bytes));
+    return OEM_OK;
+}
+
+void free_store(oem_store *s)
+{
+    if (!s) return;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    hipFree(s->csr.row_ptr);
+    hipFree(s->csr.tid);
+    hipFree(s->csr.w32);
+    hipFree(s->csr.w64);
+    hipFree(s->theta);
+    hipFree(s->cnt);
+    hipFree(s->d_state);
+    hipFree(s->d_row_w);
+    if (s->h_state) hipHostFree(s->h_state);
+    if (s->h_pinned) hipHostFree(s->h_pinned);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
+                      const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
+                      int device, const oem_store_opts *opts, oem_store *s)
+{
+    (void)opts;
+    s->device = device;
+    OEM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    DeviceCsr &m = s->csr;
+    m.n_reads = n_reads;
+    m.nnz = nnz;
+    m.n_txps = n_txps;
+    m.wide_ptr = nnz >= (1ull << 32);
+    m.w_is_f64 = cov_prob != nullptr;
+
+    if (m.wide_ptr) {
+        uint64_t *d = nullptr;
+        OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
+        m.row_ptr = d;
+        OEM_HIP(hipMemcpy(d, row_ptr, sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint32_t> rp(n_reads + 1);
+        for (uint64_t i = 0; i <= n_reads; ++i) rp[i] = (uint32_t)row_ptr[i];
+        uint32_t *d = nullptr;
+        OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
+        m.row_ptr = d;
+        OEM_HIP(hipMemcpy(d, rp.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice));
+    }
+    OEM_TRY(dev_alloc(&m.tid, nnz, &s->hbm_bytes));
+    OEM_HIP(hipMemcpy(m.tid, tid, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
+    if (m.w_is_f64) {
+        // em.rs:107-111: prev * (p as f64) * cov; w = (p as f64) * cov is the
+        // iteration-invariant factor (SURVEY.md 8a note 2: f64 keeps strict parity).
+        std::vector<double> w(nnz);
+        for (uint64_t j = 0; j < nnz; ++j) w[j] = (double)as_prob[j] * cov_prob[j];
+        OEM_TRY(dev_alloc(&m.w64, nnz, &s->hbm_bytes));
+        OEM_HIP(hipMemcpy(m.w64, w.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+    } else {
+        OEM_TRY(dev_alloc(&m.w32, nnz, &s->hbm_bytes));
+        OEM_HIP(hipMemcpy(m.w32, as_prob, sizeof(float) * nnz, hipMemcpyHostToDevice));
+    }
+    OEM_TRY(dev_alloc(&s->theta, n_txps, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&s->cnt, n_txps, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&s->d_state, 1, &s->hbm_bytes));
+    OEM_HIP(hipHostMalloc((void **)&s->h_state, sizeof(EmState), hipHostMallocDefault));
+    OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (n_txps ? n_txps : 1), hipHostMallocDefault));
+    s->global_n_reads = n_reads;
+    s->global_row_offset = 0;
+    return OEM_OK;
+}
+
+} // namespace
+} // namespace oem
+
+using namespace oem;
+
+// ---------------------------------------------------------------------------
+// library
+// ---------------------------------------------------------------------------
+extern "C" int oem_abi_version(void) { return OEM_ABI_VERSION; }
+
+extern "C" const char *oem_last_error(void) { return t_err; }
+
+extern "C" int oem_device_count(int *out_count)
+{
+    if (!out_count) return fail(OEM_ERR_ARG, "oem_device_count: out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *out_count = n;
+    return OEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// store
+// ---------------------------------------------------------------------------
+extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
+                                const double *cov_prob, uint64_t n_reads, uint64_t nnz,
+                                uint32_t n_txps, int device, const oem_store_opts *opts,
+                                oem_store **out)
+{
+    if (!out) return fail(OEM_ERR_ARG, "oem_store_create: out is NULL");
+    *out = nullptr;
+    if (!row_ptr) return fail(OEM_ERR_ARG, "oem_store_create: row_ptr is NULL");
+    if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_store_create: tid/as_prob is NULL");
+    if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_store_create: n_txps is 0");
+    OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps));
+    OEM_TRY(ensure_device(device));
+    oem_store *s = new (std::nothrow) oem_store();
+    if (!s) return fail(OEM_ERR_OOM, "oem_store_create: host allocation failed");
+    int rc = create_store_impl(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, opts, s);
+    if (rc != OEM_OK) {
+        free_store(s);
+        return rc;
+    }
+    *out = s;
+    return OEM_OK;
+}
+
+extern "C" void oem_store_destroy(oem_store *store) { free_store(store); }
+
+extern "C" int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uint32_t *n_txps)
+{
+    if (!store) return fail(OEM_ERR_ARG, "oem_store_dims: store is NULL");
+    if (n_reads) *n_reads = store->csr.n_reads;
+    if (nnz) *nnz = store->csr.nnz;
+    if (n_txps) *n_txps = store->csr.n_txps;
+    return OEM_OK;
+}
+
+extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass)
+{
+    if (!store) return fail(OEM_ERR_ARG, "oem_store_bytes: store is NULL");
+    const DeviceCsr &m = store->csr;
+    if (hbm_bytes) *hbm_bytes = store->hbm_bytes;
+    if (algorithmic_bytes_per_pass)
+        // nnz*(4 [tid] + 4|8 [w]) + (R+1)*4|8 [row_ptr] + 2*T*8 [theta read, cnt written]
+        *algorithmic_bytes_per_pass = m.nnz * (4 + (m.w_is_f64 ? 8 : 4)) +
+                                      (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) + 2ull * m.n_txps * 8;
+    return OEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// EM
+// ---------------------------------------------------------------------------
+extern "C" int oem_m_step(oem_store *s, const double *theta, const uint32_t *row_w, double *out_counts)
+{
+    if (!s || !theta || !out_counts) return fail(OEM_ERR_ARG, "oem_m_step: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const uint32_t T = s->csr.n_txps;
+    OEM_HIP(hipMemcpyAsync(s->theta, theta, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    const uint32_t *d_w = nullptr;
+    if (row_w) {
+        OEM_TRY(ensure_row_w(s));
+        OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w, sizeof(uint32_t) * s->csr.n_reads, hipMemcpyHostToDevice, s->stream));
+        d_w = s->d_row_w;
+    }
+    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, d_w, 0, s->csr.n_reads));
+    if (s->comm && comm_size(s->comm) > 1)
+        OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
+    return copy_counts_out(s, out_counts);
+}
+
+extern "C" int oem_em_run(oem_store *s, const double *init_abundances, uint32_t max_iter,
+                          double conv_thresh, uint32_t min_iter_gate, double *out_counts,
+                          oem_run_info *info)
+{
+    if (!s || !out_counts) return fail(OEM_ERR_ARG, "oem_em_run: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    RunArgs a;
+    a.init = init_abundances;
+    a.row_begin = 0;
+    a.row_end = s->csr.n_reads;
+    a.total_reads = s->global_n_reads;
+    a.max_iter = max_iter;
+    a.conv_thresh = conv_thresh;
+    a.min_iter_gate = min_iter_gate;
+    OEM_TRY(run_em_device(s, a, info));
+    return copy_counts_out(s, out_counts);
+}
+
+// ---------------------------------------------------------------------------
+// bootstrap
+// ---------------------------------------------------------------------------
+extern "C" int oem_bootstrap_weights(oem_store *s, uint64_t seed, uint32_t replica, uint32_t *out_row_w)
+{
+    if (!s || !out_row_w) return fail(OEM_ERR_ARG, "oem_bootstrap_weights: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    OEM_TRY(ensure_row_w(s));
+    OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, s->csr.n_reads, s->global_row_offset,
+                                     s->global_n_reads, seed, replica));
+    OEM_HIP(hipMemcpyAsync(out_row_w, s->d_row_w, sizeof(uint32_t) * s->csr.n_reads, hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    return OEM_OK;
+}
+
+extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all,
+                             const double *init_abundances, uint32_t max_iter, double conv_thresh,
+                             double *out, oem_run_info *infos)
+{
+    if (!s || (n_boot && !out)) return fail(OEM_ERR_ARG, "oem_bootstrap: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    OEM_TRY(ensure_row_w(s));
+    const uint32_t T = s->csr.n_txps;
+    const uint64_t R = s->csr.n_reads;
+    for (uint32_t b = 0; b < n_boot; ++b) {
+        if (row_w_all) {
+            OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (uint64_t)b * R, sizeof(uint32_t) * R,
+                                   hipMemcpyHostToDevice, s->stream));
+        } else {
+            OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset,
+                                             s->global_n_reads, seed, b)); // em.rs:274-276
+        }
+        RunArgs a;
+        a.init = init_abundances;
+        a.d_row_w = s->d_row_w;
+        a.row_begin = 0;
+        a.row_end = R;
+        a.total_reads = s->global_n_reads; // em.rs:154: still the store's read count
+        a.max_iter = max_iter;
+        a.conv_thresh = conv_thresh;
+        a.min_iter_gate = 50;              // do_bootstrap -> do_em (em.rs:289, :212)
+        OEM_TRY(run_em_device(s, a, infos ? &infos[b] : nullptr));
+        OEM_TRY(copy_counts_out(s, out + (uint64_t)b * T));
+    }
+    return OEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// single-cell batch (v1: cells run back to back on the resident matrix)
+// ---------------------------------------------------------------------------
+extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, const uint64_t *row_ptr,
+                                const uint32_t *tid, const float *as_prob, const double *cov_prob,
+                                uint64_t n_reads, uint64_t nnz, uint32_t n_txps, int device,
+                                uint32_t max_iter, double conv_thresh, double *out,
+                                oem_run_info *infos)
+{
+    if (!cell_row_off || (n_cells && !out)) return fail(OEM_ERR_ARG, "oem_em_run_cells: NULL argument");
+    if (cell_row_off[0] != 0 || cell_row_off[n_cells] != n_reads)
+        return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off must span [0, n_reads]");
+    for (uint32_t c = 0; c < n_cells; ++c)
+        if (cell_row_off[c + 1] < cell_row_off[c])
+            return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off not non-decreasing at cell %u", c);
+    oem_store *s = nullptr;
+    OEM_TRY(oem_store_create(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, nullptr, &s));
+    int rc = OEM_OK;
+    for (uint32_t c = 0; c < n_cells && rc == OEM_OK; ++c) {
+        RunArgs a;
+        a.row_begin = cell_row_off[c];
+        a.row_end = cell_row_off[c + 1];
+        a.total_reads = a.row_end - a.row_begin; // the cell's own store.len() (single_cell.rs:122-130)
+        a.max_iter = max_iter;
+        a.conv_thresh = conv_thresh;
+        a.min_iter_gate = 50;                    // em::em (single_cell.rs:150)
+        rc = run_em_device(s, a, infos ? &infos[c] : nullptr);
+        if (rc == OEM_OK) rc = copy_counts_out(s, out + (uint64_t)c * n_txps);
+    }
+    free_store(s);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU
+// ---------------------------------------------------------------------------
+extern "C" int oem_store_attach_comm(oem_store *s, oem_comm *comm, uint64_t global_n_reads,
+                                     uint64_t global_row_offset)
+{
+    if (!s) return fail(OEM_ERR_ARG, "oem_store_attach_comm: store is NULL");
+    if (global_row_offset + s->csr.n_reads > global_n_reads)
+        return fail(OEM_ERR_ARG, "oem_store_attach_comm: shard [%llu,+%llu) exceeds %llu reads",
+                    (unsigned long long)global_row_offset, (unsigned long long)s->csr.n_reads,
+                    (unsigned long long)global_n_reads);
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->comm = reinterpret_cast<Comm *>(comm);
+    s->global_n_reads = global_n_reads;
+    s->global_row_offset = global_row_offset;
+    return OEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg_ms)
+{
+    if (!s || !out_avg_ms || n_launches == 0) return fail(OEM_ERR_ARG, "oem_time_m_step: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const uint32_t T = s->csr.n_txps;
+    OEM_TRY(launch_fill(s, s->theta, (double)s->global_n_reads / (double)T, T));
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    hipEvent_t e0, e1;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    // one untimed launch to page the kernel in
+    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, nullptr, 0, s->csr.n_reads));
+    OEM_HIP(hipEventRecord(e0, s->stream));
+    for (uint32_t k = 0; k < n_launches; ++k)
+        OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, nullptr, 0, s->csr.n_reads));
+    OEM_HIP(hipEventRecord(e1, s->stream));
+    OEM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *out_avg_ms = ms / (float)n_launches;
+    return OEM_OK;
+}
+
+extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
+{
+    if (!s || !out_ms) return fail(OEM_ERR_ARG, "oem_time_em_iters: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const uint32_t T = s->csr.n_txps;
+    RunArgs a;
+    a.row_end = s->csr.n_reads;
+    a.total_reads = s->global_n_reads;
+    a.max_iter = n_iters;
+    a.conv_thresh = -1.0; // rel_diff >= 0 is never < -1: no early exit (SURVEY.md 8a note 3)
+    EmParams p{T, a.max_iter, 0xffffffffu, a.conv_thresh};
+    OEM_TRY(launch_fill(s, s->theta, (double)a.total_reads / (double)T, T));
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
+    hipEvent_t e0, e1;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    OEM_HIP(hipEventRecord(e0, s->stream));
+    for (uint32_t k = 0; k < n_iters; ++k) OEM_TRY(enqueue_iteration(s, a, p));
+    OEM_HIP(hipEventRecord(e1, s->stream));
+    OEM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *out_ms = ms;
+    return OEM_OK;
+}

@@ -1,0 +1,151 @@
+// oem_comm.cpp -- RCCL communicator over the row shards of one node.
+//
+// One process per GPU; each process owns one row shard of the alignment store
+// and the only exchange of the path is the sum of the n_txps partial counts
+// per E/M pass (in the reference this is the shared
+// Vec<AtomicF64> of em.rs:338-341).  RCCL is loaded lazily with dlopen so a
+// single-GPU user never pays for (or needs) librccl: if the host process has
+// already loaded an RCCL (PyTorch ships one with the same SONAME) that copy is
+// reused, so there is exactly one RCCL per process.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "oem_internal.h"
+
+namespace oem {
+
+namespace {
+
+// Minimal slice of the RCCL API (rccl.h); types reduced to what crosses here.
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+constexpr int kNcclSum = 0;     // ncclSum
+constexpr int kNcclFloat64 = 8; // ncclFloat64 / ncclDouble
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_api;
+std::mutex g_api_mu;
+
+int load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_api_mu);
+    if (g_api.handle) return OEM_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); // reuse the host's copy if there is one
+        if (h) break;
+    }
+    if (!h) {
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+    }
+    if (!h) return fail(OEM_ERR_RCCL, "cannot load librccl: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce)
+        return fail(OEM_ERR_RCCL, "librccl lacks a required symbol");
+    g_api = a;
+    return OEM_OK;
+}
+
+const char *nccl_err(ncclResult_t r)
+{
+    return g_api.GetErrorString ? g_api.GetErrorString(r) : "rccl error";
+}
+
+} // namespace
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0;
+    int n_ranks = 1;
+    int device = 0;
+};
+
+int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
+{
+    if (!c || c->n_ranks == 1) {
+        if (send != recv)
+            OEM_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return OEM_OK;
+    }
+    ncclResult_t r = g_api.AllReduce(send, recv, count, kNcclFloat64, kNcclSum, c->comm, st);
+    if (r != 0) return fail(OEM_ERR_RCCL, "ncclAllReduce: %s", nccl_err(r));
+    return OEM_OK;
+}
+
+int comm_rank(const Comm *c) { return c ? c->rank : 0; }
+int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }
+
+} // namespace oem
+
+using namespace oem;
+
+static_assert(sizeof(ncclUniqueId) == OEM_UNIQUE_ID_BYTES, "unique id size");
+
+extern "C" int oem_comm_unique_id(void *out_id)
+{
+    if (!out_id) return fail(OEM_ERR_ARG, "oem_comm_unique_id: out_id is NULL");
+    OEM_TRY(load_rccl());
+    ncclUniqueId id;
+    ncclResult_t r = g_api.GetUniqueId(&id);
+    if (r != 0) return fail(OEM_ERR_RCCL, "ncclGetUniqueId: %s", nccl_err(r));
+    std::memcpy(out_id, &id, sizeof(id));
+    return OEM_OK;
+}
+
+extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int device,
+                               oem_comm **out)
+{
+    if (!out) return fail(OEM_ERR_ARG, "oem_comm_create: out is NULL");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(OEM_ERR_ARG, "oem_comm_create: rank %d of %d", rank, n_ranks);
+    Comm *c = new (std::nothrow) Comm();
+    if (!c) return fail(OEM_ERR_OOM, "oem_comm_create: host allocation failed");
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->device = device;
+    if (n_ranks > 1) {
+        if (!unique_id) { delete c; return fail(OEM_ERR_ARG, "oem_comm_create: unique_id is NULL"); }
+        int rc = load_rccl();
+        if (rc != OEM_OK) { delete c; return rc; }
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(OEM_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        }
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof(id));
+        ncclResult_t r = g_api.CommInitRank(&c->comm, n_ranks, id, rank);
+        if (r != 0) { delete c; return fail(OEM_ERR_RCCL, "ncclCommInitRank: %s", nccl_err(r)); }
+    }
+    *out = reinterpret_cast<oem_comm *>(c);
+    return OEM_OK;
+}
+
+extern "C" void oem_comm_destroy(oem_comm *comm)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c) return;
+    if (c->comm && g_api.CommDestroy) g_api.CommDestroy(c->comm);
+    delete c;
+}

@@ -1,0 +1,128 @@
+// oem_internal.h -- shared declarations of the MI355X EM engine (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/oarfish_em.h"
+
+namespace oem {
+
+// ---------------------------------------------------------------------------
+// error plumbing: every ABI entry point funnels through these
+// ---------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define OEM_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ::oem::fail(_e == hipErrorOutOfMemory ? OEM_ERR_OOM : OEM_ERR_HIP,      \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                               __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define OEM_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != OEM_OK) return _rc; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Device-resident loop state of one EM problem (em.rs:169-170 rel_diff, niter).
+// Lives in HBM so that the host never sits inside the iteration loop: the
+// rel-diff kernel takes the reference's stopping decision on the device and
+// every later launch of the same run turns into a no-op once `done` is set.
+// ---------------------------------------------------------------------------
+struct EmState {
+    unsigned long long rel_bits; // running max of rel-diff this pass, as the bit pattern of a non-negative f64
+    double last_rel;             // rel_diff of the last completed loop pass
+    uint32_t niter;              // em.rs:170
+    uint32_t n_passes;           // E/M passes executed so far
+    uint32_t done;               // loop has exited (break or niter == max_iter)
+    uint32_t converged;          // exit was through `break`
+    uint32_t blocks_arrived;     // last-block election counter of the rel-diff kernel
+    uint32_t pad[3];
+};
+static_assert(sizeof(EmState) == 48, "EmState layout");
+
+// Parameters that do not change during a run.
+struct EmParams {
+    uint32_t n_txps;
+    uint32_t max_iter;
+    uint32_t min_iter_gate;
+    double conv_thresh;
+};
+
+// ---------------------------------------------------------------------------
+// The alignment store as laid out in HBM.
+//
+// v1 layout ("CSR"): row_ptr (u32 when nnz < 2^32, else u64), tid u32[nnz],
+// w f32[nnz] (== as_prob; exact) or w64 f64[nnz] (== (f64)as_prob * cov_prob when
+// the coverage model is on, em.rs:107-111).
+// ---------------------------------------------------------------------------
+struct DeviceCsr {
+    uint64_t n_reads = 0;
+    uint64_t nnz = 0;
+    uint32_t n_txps = 0;
+    bool wide_ptr = false; // row_ptr is u64
+    bool w_is_f64 = false; // coverage model on
+    void *row_ptr = nullptr;
+    uint32_t *tid = nullptr;
+    float *w32 = nullptr;
+    double *w64 = nullptr;
+};
+
+struct Comm; // oem_comm.cpp
+
+} // namespace oem
+
+struct oem_store {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    oem::DeviceCsr csr;
+    // working set of one EM problem
+    double *theta = nullptr;             // prev_counts, n_txps f64
+    double *cnt = nullptr;               // curr_counts (rank-local partial sums until all-reduced)
+    oem::EmState *d_state = nullptr;
+    oem::EmState *h_state = nullptr;     // pinned
+    uint32_t *d_row_w = nullptr;         // bootstrap multiplicities, n_reads u32
+    double *h_pinned = nullptr;          // pinned staging, n_txps f64
+    // multi-GPU
+    oem::Comm *comm = nullptr;
+    uint64_t global_n_reads = 0;
+    uint64_t global_row_offset = 0;
+    // bookkeeping
+    uint64_t hbm_bytes = 0;
+    std::mutex mu;
+};
+
+namespace oem {
+
+// kernels (oem_kernels.hip) -------------------------------------------------
+
+// One E/M pass over rows [row_begin, row_end) of the store: cnt += E/M(theta).
+// `cnt` must be zero on entry (the rel-diff kernel leaves it so).  With a
+// non-null `state` the launch is a no-op once state->done is set.
+int launch_em_pass(oem_store *s, const double *theta, double *cnt, const EmState *state,
+                   const uint32_t *row_w, uint64_t row_begin, uint64_t row_end);
+
+// rel-diff + swap + clear + stopping decision (em.rs:194-218 / :379-405):
+// prev <- curr, curr <- 0, state updated by the last block to arrive.
+int launch_reldiff_swap_clear(oem_store *s, double *prev, double *curr, EmState *state, EmParams p);
+
+// em.rs:238-242: prev < 1e-5 -> 0; also zeroes curr for the final pass.
+int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps);
+
+int launch_fill(oem_store *s, double *p, double v, uint64_t n);
+int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,
+                             uint64_t n_global, uint64_t seed, uint32_t replica);
+
+// RCCL (oem_comm.cpp) ---------------------------------------------------------
+int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st);
+
+} // namespace oem

@@ -1,0 +1,131 @@
+"""Row-sharded multi-GPU EM: one process per GPU, one RCCL all-reduce of the count
+vector per E/M pass.
+
+The reference is single-process (its only shared state is the ``Vec<AtomicF64>`` of
+em.rs:338-351); sharding by reads is exact because reads are independent given the
+abundances, and the only cross-read coupling is the sum into ``curr_counts``
+(em.rs:74,129).  Every rank takes the identical stopping decision from the
+identical all-reduced vector, so no second collective is needed.
+
+``RowShard`` / ``shard_rows_by_nnz`` / ``em_rowsharded`` are host logic that runs on
+any torch.distributed backend (the CPU tests drive them over ``gloo``);
+``create_comm`` wires the native library's RCCL communicator, whose unique id is
+broadcast with whatever process group the host already has.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+MIN_READ_THRESH = 1e-5   # constants.rs:1
+
+
+@dataclass
+class RowShard:
+    rank: int
+    row_begin: int
+    row_end: int
+    row_ptr: np.ndarray   # local, starts at 0
+    tid: np.ndarray
+    as_prob: np.ndarray
+    cov_prob: Optional[np.ndarray]
+
+
+def shard_bounds_by_nnz(row_ptr: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row blocks balanced by alignment count, not by read count."""
+    row_ptr = np.asarray(row_ptr, dtype=np.uint64)
+    n_reads = len(row_ptr) - 1
+    nnz = int(row_ptr[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = nnz * r // world
+        c = int(np.searchsorted(row_ptr, target, side="left"))
+        cuts.append(min(max(c, cuts[-1]), n_reads))
+    cuts.append(n_reads)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_rows_by_nnz(row_ptr, tid, as_prob, cov_prob, rank: int, world: int) -> RowShard:
+    b, e = shard_bounds_by_nnz(row_ptr, world)[rank]
+    row_ptr = np.asarray(row_ptr, dtype=np.uint64)
+    a0, a1 = int(row_ptr[b]), int(row_ptr[e])
+    return RowShard(rank, b, e, (row_ptr[b:e + 1] - row_ptr[b]).astype(np.uint64),
+                    np.asarray(tid)[a0:a1], np.asarray(as_prob)[a0:a1],
+                    None if cov_prob is None else np.asarray(cov_prob)[a0:a1])
+
+
+def em_rowsharded(local_m_step: Callable[[np.ndarray], np.ndarray],
+                  allreduce_sum: Callable[[np.ndarray], np.ndarray], n_txps: int,
+                  global_n_reads: int, init=None, max_iter: int = 1000, conv_thresh: float = 1e-3,
+                  min_iter_gate: int = 50):
+    """The loop of em.rs:144-255 with the E/M pass split into rank-local partial sums and
+    one all-reduce.  ``local_m_step(theta) -> partial counts`` over this rank's reads;
+    ``allreduce_sum(x) -> sum over ranks``.  Control flow is a function of the reduced
+    vector only, hence identical on every rank.  This is the host-driven form (used by
+    the CPU/gloo tests and by external loop drivers through ``oem_m_step``); the native
+    driver (``oem_em_run`` on a store with an attached communicator) runs the same loop
+    on the device stream."""
+    if init is not None:
+        prev = np.array(init, dtype=np.float64)
+    else:
+        prev = np.full(n_txps, global_n_reads / n_txps, dtype=np.float64)   # em.rs:165-166
+    niter, n_passes, converged, last_rel = 0, 0, False, 0.0
+    while niter < max_iter:                                                 # em.rs:181
+        curr = allreduce_sum(local_m_step(prev))
+        n_passes += 1
+        m = prev > MIN_READ_THRESH
+        rel = max(0.0, float(np.max((curr[m] - prev[m]) / prev[m]))) if m.any() else 0.0
+        prev = curr                                                         # em.rs:204-207
+        last_rel = rel
+        if rel < conv_thresh and niter > min_iter_gate:                     # em.rs:212 / :399
+            converged = True
+            break
+        niter += 1
+    prev = np.where(prev < MIN_READ_THRESH, 0.0, prev)                      # em.rs:238-242
+    out = allreduce_sum(local_m_step(prev))                                 # em.rs:245-252
+    n_passes += 1
+    return out, niter, n_passes, converged, last_rel
+
+
+class Comm:
+    """RAII wrapper of an ``oem_comm*``."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            _lib.lib().oem_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_comm(rank: int, world: int, device: int) -> Comm:
+    """Create the native RCCL communicator; the 128-byte unique id travels over the
+    already-initialised torch.distributed process group."""
+    import torch
+    import torch.distributed as dist
+    L = _lib.lib()
+    buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES)()
+    if rank == 0:
+        _lib.check(L.oem_comm_unique_id(C.addressof(buf)))
+    if world > 1:
+        backend = dist.get_backend()
+        dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES).from_buffer_copy(raw)
+    h = C.c_void_p()
+    _lib.check(L.oem_comm_create(C.addressof(buf), rank, world, device, C.byref(h)))
+    return Comm(h)

@@ -1,0 +1,183 @@
+"""Seeded synthetic alignment stores for the BASELINE.json configurations.
+
+Generator of SURVEY.md section 8d / BASELINE.md section 4 (there is no BAM or
+read data in the reference's test_data/, and no network):
+
+  * true abundance  a_t ~ LogNormal(0, 2), normalised;
+  * transcripts grouped into "genes" of size 1 + Geom(1/4), contiguous ids;
+  * per read: primary t0 ~ Categorical(a); k = clip(1 + Poisson(kbar-1), 1, 100)
+    (cap = --best-n default 100, prog_opts.rs:428); the other k-1 targets are 80 %
+    from the primary's gene and 20 % uniform over all transcripts; duplicates within
+    a read are dropped (targets are distinct);
+  * weights follow oarfish_types.rs:1107-1113: p = expf((s - best) / 5) as **f32**,
+    with d = best - s in {0, 1, ...}: d = 0 for the primary, d ~ Geom(0.15) for the
+    others, truncated so that s / best >= 0.95 (default score threshold,
+    prog_opts.rs:458) for a best score drawn uniformly from [500, 3000];
+  * optional coverage column: positive f64, normalised to sum 1 per read, as
+    normalize_probability.rs:61-69 leaves it.
+
+Rows come out in generation order (no sorting).  Reads are generated in fixed
+chunks of ``CHUNK`` reads, chunk c from ``default_rng([seed, c])``, so a store is
+a pure function of (seed, n_reads, n_txps, kbar, coverage).
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+CHUNK = 1 << 18
+BASE_SEED = 20260928
+
+
+@dataclass
+class SyntheticStore:
+    row_ptr: np.ndarray          # u64 [R+1]
+    tid: np.ndarray              # u32 [nnz]
+    as_prob: np.ndarray          # f32 [nnz]
+    cov_prob: Optional[np.ndarray]  # f64 [nnz] or None
+    n_txps: int
+    abundance: np.ndarray        # f64 [T] ground truth (sums to 1)
+    gene_of: np.ndarray          # i32 [T]
+
+    @property
+    def n_reads(self) -> int:
+        return len(self.row_ptr) - 1
+
+    @property
+    def nnz(self) -> int:
+        return len(self.tid)
+
+
+def _genes(n_txps: int, rng: np.random.Generator):
+    sizes = []
+    tot = 0
+    while tot < n_txps:
+        s = 1 + rng.geometric(0.25, size=max(1024, n_txps // 3)) - 1  # 1 + Geom(1/4) on {0,1,..}
+        sizes.append(s)
+        tot += int(s.sum())
+    sizes = np.concatenate(sizes)
+    ends = np.cumsum(sizes)
+    n_genes = int(np.searchsorted(ends, n_txps, side="left")) + 1
+    sizes = sizes[:n_genes].copy()
+    sizes[-1] -= int(ends[n_genes - 1]) - n_txps
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    gene_of = np.repeat(np.arange(n_genes, dtype=np.int32), sizes)
+    return starts, sizes.astype(np.int64), gene_of
+
+
+def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_size, gene_of,
+           coverage: bool):
+    rng = np.random.default_rng([seed, c])
+    # primary transcript ~ Categorical(a)
+    t0 = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int64)
+    np.minimum(t0, n_txps - 1, out=t0)
+    k = np.clip(1 + rng.poisson(max(kbar - 1.0, 0.0), size=n), 1, 100).astype(np.int64)
+    k = np.minimum(k, n_txps)
+    tot = int(k.sum())
+    row = np.repeat(np.arange(n, dtype=np.int64), k)
+    first = np.concatenate([[0], np.cumsum(k)[:-1]])
+    is_primary = np.zeros(tot, dtype=bool)
+    is_primary[first] = True
+    # targets: slot 0 is the primary; of the other k-1 slots Binomial(k-1, 0.8) are
+    # "same gene" slots, the rest uniform over all transcripts.  Same-gene slots walk
+    # the gene's other members from a random rotation (distinct by construction) and,
+    # once the gene is exhausted, spill to the ids that follow it (neighbouring
+    # genes), so reads keep their k alignments and their locality.
+    slot = np.arange(tot, dtype=np.int64) - first[row]
+    n_gene = rng.binomial(k - 1, 0.8)[row]
+    is_gene = (slot >= 1) & (slot <= n_gene)
+    g = gene_of[t0][row]
+    gs, gz = g_start[g], g_size[g]
+    i = slot - 1
+    rot = (rng.random(n) * 1e9).astype(np.int64)[row]
+    others = np.maximum(gz - 1, 1)
+    member = (t0[row] - gs + 1 + (rot + i) % others) % gz
+    spill = gs + gz + (i - (gz - 1))
+    spill = np.where(spill >= n_txps, gs - 1 - (spill - n_txps), spill)
+    in_gene = np.where(i < gz - 1, gs + member, spill)
+    in_gene = np.clip(in_gene, 0, n_txps - 1)
+    anywhere = rng.integers(0, n_txps, size=tot)
+    t = np.where(is_gene, in_gene, anywhere)
+    t[is_primary] = t0
+    # score deficits d (best - s): 0 for the primary, truncated geometric otherwise
+    best = rng.integers(500, 3001, size=n)
+    dmax = np.floor(0.05 * best).astype(np.int64)[row]
+    d = np.minimum(rng.geometric(0.15, size=tot) - 1, dmax)
+    d[is_primary] = 0
+    # distinct targets per read: keep the smallest deficit of each (row, tid)
+    order = np.lexsort((d, t, row))
+    row, t, d = row[order], t[order], d[order]
+    keep = np.ones(tot, dtype=bool)
+    keep[1:] = (row[1:] != row[:-1]) | (t[1:] != t[:-1])
+    row, t, d = row[keep], t[keep], d[keep]
+    # oarfish_types.rs:1112-1113: ((fscore - mscore) / score_prob_denom).exp() in f32
+    p = np.exp((-d.astype(np.float32)) / np.float32(5.0)).astype(np.float32)
+    lens = np.bincount(row, minlength=n).astype(np.uint64)
+    cov = None
+    if coverage:
+        cov = rng.uniform(0.05, 1.0, size=len(t))
+        s = np.add.reduceat(cov, np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64))
+        cov = cov / np.repeat(s, lens.astype(np.int64))
+    return lens, t.astype(np.uint32), p, cov
+
+
+def make_store(n_reads: int, n_txps: int, kbar: float = 8.0, seed: int = BASE_SEED,
+               coverage: bool = False, threads: int = 8) -> SyntheticStore:
+    rng0 = np.random.default_rng([seed, 0xA11CE])
+    a = rng0.lognormal(0.0, 2.0, size=n_txps)
+    a /= a.sum()
+    cdf = np.cumsum(a)
+    cdf /= cdf[-1]
+    g_start, g_size, gene_of = _genes(n_txps, rng0)
+    n_chunks = (n_reads + CHUNK - 1) // CHUNK
+    sizes = [min(CHUNK, n_reads - c * CHUNK) for c in range(n_chunks)]
+
+    def run(c):
+        return _chunk(c, sizes[c], seed, n_txps, kbar, cdf, g_start, g_size, gene_of, coverage)
+
+    if n_chunks > 1 and threads > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(run, range(n_chunks)))
+    else:
+        parts = [run(c) for c in range(n_chunks)]
+    lens = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, dtype=np.uint64)
+    row_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(lens, out=row_ptr[1:])
+    tid = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, dtype=np.uint32)
+    as_prob = np.concatenate([p[2] for p in parts]) if parts else np.zeros(0, dtype=np.float32)
+    cov = np.concatenate([p[3] for p in parts]) if coverage and parts else None
+    return SyntheticStore(row_ptr, tid, as_prob, cov, n_txps, a, gene_of)
+
+
+# BASELINE.json configs (C2, C3/C4, C5)
+CONFIGS = {
+    "c2": dict(n_reads=1_000_000, n_txps=60_000, kbar=8.0),
+    "c3": dict(n_reads=10_000_000, n_txps=200_000, kbar=8.0),
+    "c5_cell": dict(n_reads=50_000, n_txps=60_000, kbar=8.0),
+}
+
+
+def make_config(name: str, coverage: bool = False, seed_offset: int = 0, **over) -> SyntheticStore:
+    cfg = dict(CONFIGS[name])
+    cfg.update(over)
+    return make_store(seed=BASE_SEED + seed_offset, coverage=coverage, **cfg)
+
+
+def make_cells(n_cells: int, reads_per_cell: int, n_txps: int, kbar: float = 8.0,
+               seed: int = BASE_SEED + 5, expressed_frac: float = 0.1):
+    """C5: concatenated per-cell stores.  Each cell expresses a random subset of genes."""
+    rps, tids, ps = [np.zeros(1, dtype=np.uint64)], [], []
+    cell_off = np.zeros(n_cells + 1, dtype=np.uint64)
+    base = 0
+    for c in range(n_cells):
+        st = make_store(reads_per_cell, n_txps, kbar, seed=seed * 1000 + c, threads=1)
+        rps.append(st.row_ptr[1:] + np.uint64(base))
+        tids.append(st.tid)
+        ps.append(st.as_prob)
+        base += st.nnz
+        cell_off[c + 1] = cell_off[c] + np.uint64(st.n_reads)
+    return (cell_off, np.concatenate(rps), np.concatenate(tids) if tids else np.zeros(0, np.uint32),
+            np.concatenate(ps) if ps else np.zeros(0, np.float32))

@@ -1,0 +1,126 @@
+/*
+ * oem_oracle.h -- CPU restatement of oarfish's EM / bootstrap hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oarfish_amd/ (the product) may
+ * include, link, import or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / baseline.
+ *
+ * PARITY STATUS: "parity unpinned by the reference".  The reference
+ * (COMBINE-lab/oarfish v0.10.3, Rust) has no unit test, fixture or golden
+ * vector for src/em.rs / src/bootstrap.rs and cannot be
+ * built in this image (no cargo/rustc, no vendored crates).  The restatement
+ * is therefore pinned by (i) closed-form cases, (ii) algebraic invariants and
+ * (iii) an independent NumPy restatement (oracle/oracle_np.py), all committed
+ * as fixtures under tests/golden/.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference checkout, src/...).
+ */
+#ifndef OEM_ORACLE_H
+#define OEM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/util/constants.rs:1-2 */
+#define ORACLE_MIN_READ_THRESH 1e-5
+#define ORACLE_EM_DENOM_THRESH 1e-30
+
+/* The alignment store as em.rs consumes it (src/util/oarfish_types.rs:548-558):
+ * boundaries -> row_ptr, alignments[].ref_id -> tid, as_probabilities -> as_prob,
+ * coverage_probabilities -> cov_prob (ignored unless model_coverage). */
+typedef struct {
+    uint64_t n_reads;          /* store.len()  (oarfish_types.rs:562-564) */
+    uint64_t nnz;              /* store.total_len() */
+    uint32_t n_txps;           /* txp_info.len() */
+    const uint64_t *row_ptr;   /* n_reads+1, row_ptr[0]==0 (oarfish_types.rs:645) */
+    const uint32_t *tid;       /* AlnInfo.ref_id (oarfish_types.rs:331) */
+    const float *as_prob;      /* f32 (oarfish_types.rs:552, :1112-1113) */
+    const double *cov_prob;    /* f64 or NULL <=> !filter_opts.model_coverage */
+} oracle_store;
+
+typedef struct {
+    uint32_t niter;        /* value of `niter` when the loop exits (em.rs:170,218) */
+    uint32_t n_passes;     /* number of m_step calls incl. the final one (em.rs:183,245) */
+    uint32_t converged;    /* 1 if the loop left through `break` (em.rs:212-214) */
+    double   rel_diff;     /* rel_diff of the last completed loop pass (em.rs:194-201) */
+} oracle_run_info;
+
+/* One E/M pass.  em.rs:87-133 (m_step).
+ * `inds`==NULL  : rows 0..n_reads in order          (store.iter(), oarfish_types.rs:651-656)
+ * `inds`!=NULL  : rows inds[0..n_inds] in that order (random_sampling_iter, :658-669,576-592)
+ * `row_w`!=NULL : row i is visited once and its increments are scaled by row_w[i]
+ *                 (the multiplicity form of the sorted index list; exact in real
+ *                 arithmetic, equal up to fp summation order to the `inds` form). */
+void oracle_m_step(const oracle_store *s, const uint64_t *inds, uint64_t n_inds,
+                   const uint32_t *row_w, const double *prev, double *curr);
+
+/* The serial EM driver.  em.rs:144-255 (do_em); with min_iter_gate=50 this is
+ * em::em (em.rs:262-271), with min_iter_gate=1 it has em::em_par's stopping
+ * rule (em.rs:399).  `init`==NULL => uniform n_reads/n_txps (em.rs:160-167).
+ * Returns 0 on success. */
+int oracle_do_em(const oracle_store *s, const double *init, uint32_t max_iter,
+                 double conv_thresh, uint32_t min_iter_gate, const uint64_t *inds,
+                 uint64_t n_inds, const uint32_t *row_w, double *out_counts,
+                 oracle_run_info *info);
+
+/* em.rs:320-447 (em_par): row-parallel E/M over `nthreads` threads with a
+ * CAS-loop f64 add standing in for atomic_float::AtomicF64::fetch_add
+ * (em.rs:74), serial rel-diff (em.rs:379-386), gate niter>1 (em.rs:399). */
+int oracle_em_par(const oracle_store *s, const double *init, uint32_t max_iter,
+                  double conv_thresh, uint32_t min_iter_gate, int nthreads,
+                  double *out_counts, oracle_run_info *info);
+
+/* src/bootstrap.rs:7-16 (get_sample_inds): n draws from Uniform[0,n) with
+ * replacement, sorted ascending.  The reference seeds from the OS
+ * (em.rs:274), so only the distribution is specified; here a seeded
+ * xoshiro256** stream stands in. */
+void oracle_get_sample_inds(uint64_t n, uint64_t seed, uint64_t *out_inds);
+
+/* multiplicity form of a sorted index list: row_w[i] = #{k : inds[k]==i}. */
+void oracle_inds_to_weights(const uint64_t *inds, uint64_t n_inds, uint64_t n_reads,
+                            uint32_t *row_w);
+
+/* em.rs:292-314 (bootstrap): n_boot resampled serial EMs, one per thread
+ * (rayon over replicates), each em.rs:273-290 (do_bootstrap).
+ * `row_w_all` (n_boot x n_reads, optional) injects the resamples; otherwise
+ * they are drawn with oracle_get_sample_inds(seed + b).  out = n_boot x n_txps. */
+int oracle_bootstrap(const oracle_store *s, const double *init, uint32_t n_boot, uint64_t seed,
+                     const uint32_t *row_w_all, uint32_t max_iter, double conv_thresh,
+                     int nthreads, double *out, oracle_run_info *infos);
+
+/* src/util/aux_counts.rs:23-50 (get_aux_counts): per transcript, number of
+ * alignments (total) and number of single-alignment reads (unique). */
+void oracle_aux_counts(const oracle_store *s, uint32_t *unique_count, uint32_t *total_count);
+
+/* ---- reference-faithful memory layout, for the CPU baseline only ----------
+ * AlnInfo is {ref_id u32, start u32, end u32, prob f64, strand u8}
+ * (oarfish_types.rs:330-337) = 24 B with natural alignment; the reference
+ * streams it plus an f32 and an f64 column per alignment (36 B/nnz).  The
+ * functions below run the same arithmetic over that layout so the timed CPU
+ * baseline moves the bytes the Rust code moves. */
+typedef struct {          /* field order as rustc lays out repr(Rust): largest alignment first */
+    double prob;
+    uint32_t ref_id, start, end;
+    uint8_t strand;
+} oracle_alninfo;         /* sizeof == 24 */
+
+int oracle_do_em_aos(uint64_t n_reads, uint32_t n_txps, const uint64_t *row_ptr,
+                     const oracle_alninfo *alns, const float *as_prob, const double *cov_prob,
+                     int model_coverage, const double *init, uint32_t max_iter,
+                     double conv_thresh, uint32_t min_iter_gate, double *out_counts,
+                     oracle_run_info *info);
+
+int oracle_em_par_aos(uint64_t n_reads, uint32_t n_txps, const uint64_t *row_ptr,
+                      const oracle_alninfo *alns, const float *as_prob, const double *cov_prob,
+                      int model_coverage, const double *init, uint32_t max_iter,
+                      double conv_thresh, uint32_t min_iter_gate, int nthreads,
+                      double *out_counts, oracle_run_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

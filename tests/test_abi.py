@@ -1,0 +1,79 @@
+"""CPU tests of the C-ABI library: it builds, loads, exports every symbol the
+header declares, validates arguments and fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oarfish_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "oarfish_em.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(oem_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/oarfish_em.h but not exported"
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+    assert L.oem_abi_version() == 1
+
+
+def test_no_torch_types_in_abi():
+    src = open(os.path.join(ROOT, "include", "oarfish_em.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert "torch" not in src and "at::" not in src and "#include <hip" not in src
+
+
+def test_argument_validation_precedes_device_use():
+    L = _lib.lib()
+    h = C.c_void_p()
+    rp = np.array([0, 2, 1], dtype=np.uint64)  # decreasing
+    tid = np.array([0, 1], dtype=np.uint32)
+    p = np.array([1.0, 1.0], dtype=np.float32)
+    rc = L.oem_store_create(rp.ctypes.data, tid.ctypes.data, p.ctypes.data, None, 2, 2, 2, 0, None, C.byref(h))
+    assert rc == _lib.OEM_ERR_ARG and b"non-decreasing" in L.oem_last_error()
+    rp = np.array([0, 1, 2], dtype=np.uint64)
+    tid = np.array([0, 7], dtype=np.uint32)  # tid >= n_txps
+    rc = L.oem_store_create(rp.ctypes.data, tid.ctypes.data, p.ctypes.data, None, 2, 2, 2, 0, None, C.byref(h))
+    assert rc == _lib.OEM_ERR_ARG and b"n_txps" in L.oem_last_error()
+    rc = L.oem_store_create(None, tid.ctypes.data, p.ctypes.data, None, 2, 2, 2, 0, None, C.byref(h))
+    assert rc == _lib.OEM_ERR_ARG
+    assert L.oem_em_run(None, None, 10, 1e-3, 50, None, None) == _lib.OEM_ERR_ARG
+    assert L.oem_comm_create(None, 3, 2, 0, C.byref(h)) == _lib.OEM_ERR_ARG
+
+
+def test_fails_loudly_without_a_device():
+    """No CPU fallback: on a box without a HIP device every compute entry point errors."""
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    import oarfish_amd
+    rp = np.array([0, 1, 2], dtype=np.uint64)
+    tid = np.array([0, 1], dtype=np.uint32)
+    p = np.array([1.0, 1.0], dtype=np.float32)
+    with pytest.raises(oarfish_amd.OemError) as ei:
+        oarfish_amd.DeviceStore(rp, tid, p, None, 2)
+    assert ei.value.code == _lib.OEM_ERR_NO_DEVICE
+    st = oarfish_amd.InMemoryAlignmentStore.from_arrays(rp, tid, p)
+    emi = oarfish_amd.EMInfo(eq_map=st, txp_info=[oarfish_amd.TranscriptInfo()] * 2)
+    with pytest.raises(oarfish_amd.OemError):
+        oarfish_amd.em(emi, 1)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under oarfish_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "oarfish_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("SURVEY", ""), f"{f} mentions the oracle"

@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the
+committed golden fixtures.  Tolerance: BASELINE.json north_star -- abundances
+within 1e-4 relative of the reference algorithm (f64 arithmetic; the only
+difference allowed is floating-point summation order, so the observed error is
+~1e-12 and most checks are far tighter than 1e-4)."""
+import numpy as np
+import pytest
+
+import oarfish_amd
+from oarfish_amd import synth
+from oarfish_amd.types import DeviceStore, InMemoryAlignmentStore
+from oracle import c_oracle
+from tests.common import assert_counts_close, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north_star tolerance
+
+
+def _dev(g, **kw):
+    return DeviceStore(g["row_ptr"], g["tid"], g["as_prob"], g["cov_prob"], g["n_txps"], **kw)
+
+
+def _orc(g):
+    return c_oracle.Store(g["row_ptr"], g["tid"], g["as_prob"], g["cov_prob"], g["n_txps"])
+
+
+def test_extension_is_loaded_and_device_present():
+    from oarfish_amd import _lib
+    assert _lib.device_count() >= 1
+    assert _lib.lib().oem_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixtures(name):
+    g = load_golden(name)
+    R, T = len(g["row_ptr"]) - 1, g["n_txps"]
+    with _dev(g) as d:
+        for run in g["runs"]:
+            cnt, info = d.em_run(g["init"], run["max_iter"], run["conv_thresh"], run["gate"])
+            what = f"{name} {run['max_iter']}/{run['conv_thresh']}/{run['gate']}"
+            assert abs(info.niter - run["niter"]) <= 1, what   # knife-edge rel<thresh may flip
+            if info.niter == run["niter"]:
+                assert info.n_passes == run["n_passes"] and info.converged == run["converged"], what
+                assert_counts_close(cnt, run["counts"], R, T, 1e-9, what)
+                assert abs(info.rel_diff - run["rel_diff"]) <= 1e-6 * max(1.0, abs(run["rel_diff"])), what
+            else:
+                assert_counts_close(cnt, run["counts"], R, T, RTOL, what)
+        if "closed_form" in g:
+            cnt, _ = d.em_run(g["init"], g["runs"][-1]["max_iter"], g["runs"][-1]["conv_thresh"], 50)
+            np.testing.assert_allclose(cnt, g["closed_form"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("coverage", [False, True])
+def test_m_step_matches_oracle(coverage):
+    st = synth.make_store(50_000, 3_000, seed=77, coverage=coverage)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    rng = np.random.default_rng(1)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps) as d:
+        for trial in range(3):
+            theta = rng.lognormal(0, 2, size=st.n_txps)
+            theta[rng.random(st.n_txps) < 0.1] = 0.0
+            want = c_oracle.m_step(o, theta)
+            got = d.m_step(theta)
+            assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-10, f"m_step trial {trial}")
+        w = rng.poisson(1.0, size=st.n_reads).astype(np.uint32)
+        theta = np.full(st.n_txps, st.n_reads / st.n_txps)
+        assert_counts_close(d.m_step(theta, w), c_oracle.m_step(o, theta, row_w=w), st.n_reads,
+                            st.n_txps, 1e-10, "weighted m_step")
+
+
+@pytest.mark.parametrize("gate,thresh,max_iter", [(50, 1e-3, 1000), (1, 1e-3, 1000), (50, 0.0, 100)])
+def test_em_matches_oracle_medium(gate, thresh, max_iter):
+    st = synth.make_store(200_000, 12_000, seed=78)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    want, wi = c_oracle.do_em(o, max_iter=max_iter, conv_thresh=thresh, min_iter_gate=gate)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        got, gi = d.em_run(None, max_iter, thresh, gate)
+    assert abs(gi.niter - wi.niter) <= 1
+    assert_counts_close(got, want, st.n_reads, st.n_txps, RTOL if gi.niter != wi.niter else 1e-8, "em")
+    assert abs(got.sum() - st.n_reads) < 1e-6 * st.n_reads
+
+
+def test_reference_interface_em_em_par_bootstrap():
+    """The host mirror: EMInfo + em / em_par / bootstrap as bulk.rs:131-194 drives them."""
+    st = synth.make_store(60_000, 4_000, seed=79, coverage=True)
+    store = InMemoryAlignmentStore.from_arrays(st.row_ptr, st.tid, st.as_prob, st.cov_prob, model_coverage=True)
+    txps = [oarfish_amd.TranscriptInfo.with_len(1000)] * st.n_txps
+    emi = oarfish_amd.EMInfo(eq_map=store, txp_info=txps, max_iter=1000, convergence_thresh=1e-3)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    c_ser = oarfish_amd.em(emi, 3)
+    w_ser, i_ser = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=50)
+    assert abs(emi.last_run_info.niter - i_ser.niter) <= 1
+    assert_counts_close(c_ser, w_ser, st.n_reads, st.n_txps, RTOL, "em")
+    c_par = oarfish_amd.em_par(emi, 8)
+    w_par, i_par = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=1)
+    assert abs(emi.last_run_info.niter - i_par.niter) <= 1
+    assert_counts_close(c_par, w_par, st.n_reads, st.n_txps, RTOL, "em_par")
+    # model_coverage off => cov_prob column ignored (em.rs:108)
+    store2 = InMemoryAlignmentStore.from_arrays(st.row_ptr, st.tid, st.as_prob, st.cov_prob, model_coverage=False)
+    emi2 = oarfish_amd.EMInfo(eq_map=store2, txp_info=txps, max_iter=60, convergence_thresh=0.0)
+    o2 = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    assert_counts_close(oarfish_amd.em(emi2, 1), c_oracle.do_em(o2, max_iter=60, conv_thresh=0.0)[0],
+                        st.n_reads, st.n_txps, 1e-8, "no coverage")
+    # bootstrap with injected resamples
+    rng = np.random.default_rng(3)
+    W = np.stack([np.bincount(rng.integers(0, st.n_reads, st.n_reads), minlength=st.n_reads) for _ in range(3)]).astype(np.uint32)
+    emi.max_iter = 200
+    got = oarfish_amd.bootstrap(emi, 3, 1, row_weights=W)
+    want, infos = c_oracle.bootstrap(o, 3, row_w_all=W, max_iter=200, conv_thresh=1e-3)
+    for b in range(3):
+        assert_counts_close(got[b], want[b], st.n_reads, st.n_txps, RTOL, f"bootstrap {b}")
+
+
+def test_bootstrap_inject_golden():
+    g = load_golden("bootstrap_inject")
+    with _dev(g) as d:
+        out, infos = d.bootstrap(g["row_w"].shape[0], row_w_all=g["row_w"], max_iter=int(g["boot_params"][0]),
+                                 conv_thresh=float(g["boot_params"][1]))
+    for b in range(out.shape[0]):
+        assert_counts_close(out[b], g["boot_counts"][b], 600, 40, 1e-6, f"replicate {b}")
+
+
+def test_device_multinomial_weights():
+    """bootstrap.rs:7-16: Multinomial(n; 1/n): sum n, mean 1, var 1-1/n, P(0)=e^-1,
+    replicas independent, stream reproducible."""
+    st = synth.make_store(200_000, 2_000, seed=80)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        w0 = d.bootstrap_weights(11, 0)
+        w0b = d.bootstrap_weights(11, 0)
+        w1 = d.bootstrap_weights(11, 1)
+        w2 = d.bootstrap_weights(12, 0)
+    n = st.n_reads
+    assert np.array_equal(w0, w0b) and not np.array_equal(w0, w1) and not np.array_equal(w0, w2)
+    for w in (w0, w1, w2):
+        assert int(w.sum()) == n
+        assert abs(w.var() - (1 - 1 / n)) < 0.02
+        assert abs((w == 0).mean() - np.exp(-1)) < 0.01
+        assert abs((w == 1).mean() - np.exp(-1)) < 0.01
+        assert abs((w == 2).mean() - np.exp(-1) / 2) < 0.01
+    assert abs(np.corrcoef(w0, w1)[0, 1]) < 0.02
+    # a device-drawn bootstrap equals the oracle run on the same drawn weights
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        out, infos = d.bootstrap(2, seed=11, max_iter=120, conv_thresh=1e-3)
+    for b, w in enumerate((w0, w1)):
+        want, wi = c_oracle.do_em(o, row_w=w, max_iter=120, conv_thresh=1e-3)
+        assert abs(infos[b].niter - wi.niter) <= 1
+        assert_counts_close(out[b], want, n, st.n_txps, RTOL, f"device bootstrap {b}")
+
+
+def test_cells_match_per_cell_oracle():
+    """single_cell.rs:139-160: each cell is an independent em::em with init None."""
+    n_cells, T = 6, 500
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, 3_000, T, seed=9)
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=300, convergence_thresh=1e-3)
+    for c in range(n_cells):
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        o = c_oracle.Store(row_ptr[r0:r1 + 1] - row_ptr[r0], tid[a0:a1], p[a0:a1], None, T)
+        want, wi = c_oracle.do_em(o, max_iter=300, conv_thresh=1e-3, min_iter_gate=50)
+        assert abs(infos[c].niter - wi.niter) <= 1
+        assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
+
+
+def test_edge_cases():
+    # empty store: every count 0
+    with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:
+        cnt, info = d.em_run(None, 10, 1e-3, 50)
+        assert np.all(cnt == 0.0) and info.n_passes == 11
+    # empty rows are tolerated and contribute nothing
+    rp = np.array([0, 0, 2, 2, 3], dtype=np.uint64)
+    tid = np.array([0, 1, 1], dtype=np.uint32)
+    p = np.array([1.0, 0.5, 1.0], dtype=np.float32)
+    o = c_oracle.Store(rp, tid, p, None, 3)
+    with DeviceStore(rp, tid, p, None, 3) as d:
+        cnt, _ = d.em_run(None, 30, 0.0, 50)
+    np.testing.assert_allclose(cnt, c_oracle.do_em(o, max_iter=30, conv_thresh=0.0)[0], rtol=1e-12)
+    # denom <= 1e-30 drops the read (em.rs:115)
+    rp = np.array([0, 1, 2], dtype=np.uint64)
+    with DeviceStore(rp, np.array([0, 1], np.uint32), np.array([1.0, 1e-38], np.float32), None, 2) as d:
+        cnt, _ = d.em_run(None, 5, 0.0, 50)
+    assert cnt[0] == 1.0 and cnt[1] == 0.0
+    # max_iter = 0
+    g = load_golden("random_a")
+    with _dev(g) as d:
+        cnt, info = d.em_run(None, 0, 1e-3, 50)
+        assert info.niter == 0 and info.n_passes == 1
+        assert_counts_close(cnt, g["runs"][0]["counts"], 1500, 200, 1e-10, "max_iter 0")
+
+
+@pytest.mark.parametrize("name", ["c2"])
+def test_full_size_properties(name):
+    """BASELINE configs[1] (1M reads x 60k txps): size-independent properties + fixed-iteration
+    parity against the (multi-threaded) oracle."""
+    st = synth.make_config(name)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    u, t = c_oracle.aux_counts(o)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        cnt, info = d.em_run(None, 100, 0.0, 50)          # 100 iterations, no early exit
+        assert info.niter == 100 and info.n_passes == 101 and not info.converged
+        assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads       # mass conservation
+        assert np.all(cnt >= u - 1e-6) and np.all(cnt <= t + 1e-6)   # unique <= count <= total
+        want, wi = c_oracle.em_par(o, max_iter=100, conv_thresh=0.0, min_iter_gate=50)
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL, "c2 100 iterations")
+        # idempotence of the resident store: a second run gives the same answer
+        cnt2, _ = d.em_run(None, 100, 0.0, 50)
+        assert_counts_close(cnt2, cnt, st.n_reads, st.n_txps, 1e-9, "rerun")
+        # linearity of one pass in the row weights: E(w1) + E(w2) = E(w1 + w2)
+        rng = np.random.default_rng(2)
+        w1 = rng.integers(0, 3, st.n_reads).astype(np.uint32)
+        w2 = rng.integers(0, 3, st.n_reads).astype(np.uint32)
+        theta = cnt + 1e-3
+        a, b, c = d.m_step(theta, w1), d.m_step(theta, w2), d.m_step(theta, w1 + w2)
+        assert_counts_close(a + b, c, st.n_reads, st.n_txps, 1e-9, "linearity")
