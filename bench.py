@@ -90,25 +90,32 @@ def cpu_baseline(row_ptr, tid, p, n_txps, seconds):
     """The oracle's em_par restatement (rayon + AtomicF64 analogue) on all host cores, on a
     bounded number of iterations of the same store."""
     from oracle import c_oracle
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     s = c_oracle.Store(row_ptr, tid, p, None, n_txps)
-    t = time.perf_counter()
-    c_oracle.em_par(s, max_iter=2, conv_thresh=0.0, nthreads=cores)  # 3 passes
-    per_pass = (time.perf_counter() - t) / 3
+    # the CAS-add scatter stops scaling long before 256 threads: pick the best thread count
+    # the way a user would pick -j, on 3 passes each
+    best_t, per_pass = 1, None
+    for nt in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+        t = time.perf_counter()
+        c_oracle.em_par(s, max_iter=2, conv_thresh=0.0, nthreads=nt)  # 3 passes
+        pp = (time.perf_counter() - t) / 3
+        if per_pass is None or pp < per_pass:
+            best_t, per_pass = nt, pp
+    cores = best_t
     iters = int(max(3, min(200, seconds / max(per_pass, 1e-6))))
     t = time.perf_counter()
     c_oracle.em_par(s, max_iter=iters, conv_thresh=0.0, nthreads=cores)
     dt = time.perf_counter() - t
     par = iters / dt  # iters loop iterations (+1 final pass, counted against us)
     # serial em::em semantics, 1 core, fewer iterations
-    it1 = max(2, iters // max(cores // 2, 1))
+    it1 = max(2, min(iters, int(3.0 / max(per_pass, 1e-6) / 8) + 2))
     t = time.perf_counter()
     c_oracle.do_em(s, max_iter=it1, conv_thresh=0.0)
     ser = it1 / (time.perf_counter() - t)
     return dict(value=par, unit="EM iterations/s", cores=cores, kind="port",
                 sample=f"{iters} iterations of the em_par restatement (oracle/oem_oracle.c, OpenMP "
-                       f"row-parallel + CAS f64 add, 8 B/nnz SoA) over the full store, {cores} threads",
-                serial_1core_value=ser)
+                       f"row-parallel + CAS f64 add, 8 B/nnz SoA) over the full store, best of 8..{ncpu} threads = {cores}",
+                serial_1core_value=ser, host_cpus=ncpu)
 
 
 def main():

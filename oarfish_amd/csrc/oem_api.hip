@@ -94,10 +94,30 @@ struct RunArgs {
     uint32_t min_iter_gate = 50;
 };
 
+bool use_tiled(const oem_store *s, const RunArgs &a)
+{
+    return s->tiled.present && a.row_begin == 0 && a.row_end == s->csr.n_reads;
+}
+
+// E/M pass theta -> cnt with whichever layout covers the request
+int enqueue_pass(oem_store *s, const RunArgs &a, const EmState *state)
+{
+    if (use_tiled(s, a))
+        return launch_em_pass_tiled(s, s->theta, s->cnt, state, a.d_row_w ? s->tiled.row_w_perm : nullptr);
+    return launch_em_pass(s, s->theta, s->cnt, state, a.d_row_w, a.row_begin, a.row_end);
+}
+
+// bootstrap multiplicities arrive in the caller's read order; the tiles want them permuted
+int prepare_row_w(oem_store *s, const RunArgs &a)
+{
+    if (a.d_row_w && use_tiled(s, a)) return launch_permute_row_w(s, a.d_row_w, s->tiled.row_w_perm);
+    return OEM_OK;
+}
+
 // one loop iteration on the stream: E/M pass, (all-reduce), rel-diff/swap/clear
 int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
 {
-    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, s->d_state, a.d_row_w, a.row_begin, a.row_end));
+    OEM_TRY(enqueue_pass(s, a, s->d_state));
     if (s->comm && comm_size(s->comm) > 1)
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, p.n_txps, s->stream));
     OEM_TRY(launch_reldiff_swap_clear(s, s->theta, s->cnt, s->d_state, p));
@@ -120,6 +140,7 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
     OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
     OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
     std::memset(s->h_state, 0, sizeof(EmState));
+    OEM_TRY(prepare_row_w(s, a));
 
     // The stopping rule cannot fire before niter > gate, so the first look at
     // the device state is due after gate+2 passes; afterwards every `kChunk`.
@@ -136,7 +157,7 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
     }
 
     OEM_TRY(launch_zero_small(s, s->theta, s->cnt, T));                                  // em.rs:238-242
-    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, a.d_row_w, a.row_begin, a.row_end)); // em.rs:245-252
+    OEM_TRY(enqueue_pass(s, a, nullptr));                                                 // em.rs:245-252
     if (s->comm && comm_size(s->comm) > 1)
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
     if (info) {
@@ -173,6 +194,13 @@ void free_store(oem_store *s)
     hipFree(s->csr.tid);
     hipFree(s->csr.w32);
     hipFree(s->csr.w64);
+    {
+        oem::DeviceTiled &t = s->tiled;
+        hipFree(t.tiles); hipFree(t.slices); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
+        hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
+        hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.queue);
+        hipFree(t.row_w_perm);
+    }
     hipFree(s->theta);
     hipFree(s->cnt);
     hipFree(s->d_state);
@@ -183,11 +211,49 @@ void free_store(oem_store *s)
     delete s;
 }
 
+template <typename T>
+int upload_vec(T **dst, const std::vector<T> &v, uint64_t *acct)
+{
+    OEM_TRY(dev_alloc(dst, v.size(), acct));
+    if (!v.empty()) OEM_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return OEM_OK;
+}
+
+int upload_tiled(oem_store *s, const TiledHost &h)
+{
+    DeviceTiled &t = s->tiled;
+    t.n_tiles = h.n_tiles;
+    t.n_buckets = h.n_buckets;
+    t.n_rows = h.n_rows;
+    t.n_local = h.n_local;
+    t.n_remote = h.n_remote;
+    OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.slices, h.slices, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.perm, h.perm, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.codes, h.codes, &s->hbm_bytes));
+    if (s->csr.w_is_f64) {
+        OEM_TRY(upload_vec(&t.w64, h.w64, &s->hbm_bytes));
+        OEM_TRY(upload_vec(&t.r_w64, h.r_w64, &s->hbm_bytes));
+    } else {
+        OEM_TRY(upload_vec(&t.w32, h.w32, &s->hbm_bytes));
+        OEM_TRY(upload_vec(&t.r_w32, h.r_w32, &s->hbm_bytes));
+    }
+    OEM_TRY(upload_vec(&t.r_tid, h.r_tid, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.r_row, h.r_row, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.r_slot, h.r_slot, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.q_dst, h.q_dst, &s->hbm_bytes));
+    OEM_TRY(upload_vec(&t.bucket_base, h.bucket_base, &s->hbm_bytes));
+    t.h_bucket_base = h.bucket_base;
+    OEM_TRY(dev_alloc(&t.queue, h.n_remote, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&t.row_w_perm, h.n_rows, &s->hbm_bytes));
+    t.present = true;
+    return OEM_OK;
+}
+
 int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                       const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
                       int device, const oem_store_opts *opts, oem_store *s)
 {
-    (void)opts;
     s->device = device;
     OEM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     DeviceCsr &m = s->csr;
@@ -230,6 +296,18 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (n_txps ? n_txps : 1), hipHostMallocDefault));
     s->global_n_reads = n_reads;
     s->global_row_offset = 0;
+
+    // default: lay the store out in primary-sorted tiles (oem_layout.h)
+    const uint32_t reorder = opts ? opts->reorder_rows : 0;
+    if (reorder != 1 && n_reads > 0) {
+        TiledHost h;
+        const char *err = nullptr;
+        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err)) {
+            OEM_TRY(upload_tiled(s, h));
+        } else if (reorder == 2) {
+            return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
+        }
+    }
     return OEM_OK;
 }
 
@@ -321,7 +399,11 @@ extern "C" int oem_m_step(oem_store *s, const double *theta, const uint32_t *row
         OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w, sizeof(uint32_t) * s->csr.n_reads, hipMemcpyHostToDevice, s->stream));
         d_w = s->d_row_w;
     }
-    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, d_w, 0, s->csr.n_reads));
+    RunArgs a;
+    a.d_row_w = d_w;
+    a.row_end = s->csr.n_reads;
+    OEM_TRY(prepare_row_w(s, a));
+    OEM_TRY(enqueue_pass(s, a, nullptr));
     if (s->comm && comm_size(s->comm) > 1)
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
     return copy_counts_out(s, out_counts);
@@ -411,7 +493,10 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         if (cell_row_off[c + 1] < cell_row_off[c])
             return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off not non-decreasing at cell %u", c);
     oem_store *s = nullptr;
-    OEM_TRY(oem_store_create(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, nullptr, &s));
+    oem_store_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    opts.reorder_rows = 1; // cells are row ranges of the caller-order CSR
+    OEM_TRY(oem_store_create(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, &opts, &s));
     int rc = OEM_OK;
     for (uint32_t c = 0; c < n_cells && rc == OEM_OK; ++c) {
         RunArgs a;
@@ -460,11 +545,12 @@ extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg
     hipEvent_t e0, e1;
     OEM_HIP(hipEventCreate(&e0));
     OEM_HIP(hipEventCreate(&e1));
+    RunArgs a;
+    a.row_end = s->csr.n_reads;
     // one untimed launch to page the kernel in
-    OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, nullptr, 0, s->csr.n_reads));
+    OEM_TRY(enqueue_pass(s, a, nullptr));
     OEM_HIP(hipEventRecord(e0, s->stream));
-    for (uint32_t k = 0; k < n_launches; ++k)
-        OEM_TRY(launch_em_pass(s, s->theta, s->cnt, nullptr, nullptr, 0, s->csr.n_reads));
+    for (uint32_t k = 0; k < n_launches; ++k) OEM_TRY(enqueue_pass(s, a, nullptr));
     OEM_HIP(hipEventRecord(e1, s->stream));
     OEM_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -6,8 +6,10 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/oarfish_em.h"
+#include "oem_layout.h"
 
 namespace oem {
 
@@ -77,6 +79,32 @@ struct DeviceCsr {
     double *w64 = nullptr;
 };
 
+// The tiled layout (oem_layout.h) resident in HBM.
+struct DeviceTiled {
+    bool present = false;
+    uint32_t n_tiles = 0;
+    uint32_t n_buckets = 0;
+    uint64_t n_rows = 0;    // non-empty reads == length of perm
+    uint64_t n_local = 0;
+    uint64_t n_remote = 0;
+    TileDesc *tiles = nullptr;
+    SliceDesc *slices = nullptr;
+    uint32_t *perm = nullptr;
+    uint32_t *codes = nullptr;
+    float *w32 = nullptr;
+    double *w64 = nullptr;
+    uint32_t *r_tid = nullptr;
+    float *r_w32 = nullptr;
+    double *r_w64 = nullptr;
+    uint16_t *r_row = nullptr;
+    uint32_t *r_slot = nullptr;
+    uint16_t *q_dst = nullptr;
+    uint32_t *bucket_base = nullptr;
+    std::vector<uint32_t> h_bucket_base;
+    double *queue = nullptr;      // n_remote f64: increments of the remote alignments, bucket-major
+    uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
+};
+
 struct Comm; // oem_comm.cpp
 
 } // namespace oem
@@ -85,6 +113,7 @@ struct oem_store {
     int device = 0;
     hipStream_t stream = nullptr;
     oem::DeviceCsr csr;
+    oem::DeviceTiled tiled;
     // working set of one EM problem
     double *theta = nullptr;             // prev_counts, n_txps f64
     double *cnt = nullptr;               // curr_counts (rank-local partial sums until all-reduced)
@@ -117,6 +146,12 @@ int launch_reldiff_swap_clear(oem_store *s, double *prev, double *curr, EmState 
 
 // em.rs:238-242: prev < 1e-5 -> 0; also zeroes curr for the final pass.
 int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps);
+
+// Tiled E/M pass over the whole store (oem_layout.h): tile kernel + remote-bucket kernel.
+// row_w is in the caller's read order; it is permuted into tile order first.
+int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
+                         const uint32_t *row_w_perm);
+int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_perm);
 
 int launch_fill(oem_store *s, double *p, double v, uint64_t n);
 int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,

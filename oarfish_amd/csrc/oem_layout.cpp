@@ -1,0 +1,291 @@
+// oem_layout.cpp -- one-off host pass that lays the alignment store out for the
+// tile kernels (see oem_layout.h).  Runs once per store at upload, the analogue
+// of the store being built once by alignment_parser.rs before the EM starts.
+#include "oem_layout.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace oem {
+
+namespace {
+
+template <typename F>
+void parallel_for(uint32_t n, F fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    if (n < 64 || nt == 1) {
+        for (uint32_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint32_t b = next.fetch_add(16);
+            if (b >= n) return;
+            const uint32_t e = std::min(n, b + 16);
+            for (uint32_t i = b; i < e; ++i) fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+}
+
+struct TileSizes {
+    uint32_t n_slices = 0;
+    uint64_t w_slots = 0;    // units of 64 weights
+    uint64_t c_slots = 0;    // units of 64 packed code pairs
+    uint32_t remote_cnt = 0;
+    uint32_t win_len = 1;
+};
+
+struct RemoteRec {
+    uint32_t tid;
+    uint16_t row;
+    uint64_t j; // index into the caller's arrays
+};
+
+} // namespace
+
+bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
+                        const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
+                        TiledHost *out, const char **err)
+{
+    (void)nnz;
+    if (n_reads >= (1ull << 32)) {
+        *err = "tiled layout needs n_reads < 2^32";
+        return false;
+    }
+    const uint32_t R = (uint32_t)n_reads;
+    const uint32_t n_buckets = (n_txps + kBucket - 1) / kBucket;
+    out->n_buckets = n_buckets;
+
+    // 1. anchor transcript of every read: the alignment that has the most of the read's
+    //    other alignments within +-kMargin transcripts (ties: larger weight, then smaller
+    //    id).  For a read that maps inside one gene family this is the family; a stray
+    //    high-scoring hit elsewhere does not drag the read away from it.
+    std::vector<uint32_t> key(R);
+    std::vector<uint32_t> hist((size_t)n_txps + 1, 0);
+    {
+        const uint32_t nblk = (R + 65535) / 65536;
+        parallel_for(nblk, [&](uint32_t blk) {
+            const uint32_t b = blk * 65536, e = std::min(R, b + 65536);
+            for (uint32_t r = b; r < e; ++r) {
+                const uint64_t s = row_ptr[r], t = row_ptr[r + 1];
+                if (s == t) { key[r] = 0xffffffffu; continue; }
+                uint64_t best = s;
+                uint32_t best_n = 0;
+                double best_w = -1.0;
+                for (uint64_t j = s; j < t; ++j) {
+                    const uint32_t tj = tid[j];
+                    uint32_t n = 0;
+                    for (uint64_t i = s; i < t; ++i) {
+                        const uint32_t d = tid[i] > tj ? tid[i] - tj : tj - tid[i];
+                        n += d <= kMargin;
+                    }
+                    const double w = cov_prob ? (double)as_prob[j] * cov_prob[j] : (double)as_prob[j];
+                    if (n > best_n || (n == best_n && (w > best_w || (w == best_w && tj < tid[best])))) {
+                        best = j; best_n = n; best_w = w;
+                    }
+                }
+                key[r] = tid[best];
+            }
+        });
+    }
+    uint32_t n_rows = 0;
+    for (uint32_t r = 0; r < R; ++r)
+        if (key[r] != 0xffffffffu) { hist[key[r] + 1]++; ++n_rows; }
+    for (uint32_t t = 0; t < n_txps; ++t) hist[t + 1] += hist[t];
+    out->n_rows = n_rows;
+
+    // 2. stable counting sort of the non-empty reads by primary
+    std::vector<uint32_t> order(n_rows);
+    {
+        std::vector<uint32_t> cur(hist.begin(), hist.end() - 1);
+        for (uint32_t r = 0; r < R; ++r)
+            if (key[r] != 0xffffffffu) order[cur[key[r]]++] = r;
+    }
+
+    // 3. tile boundaries: <= kTileRows reads, primaries within the window
+    std::vector<uint32_t> tile_start; // positions in `order`
+    std::vector<uint32_t> tile_lo;
+    {
+        uint32_t pos = 0;
+        while (pos < n_rows) {
+            const uint32_t k0 = key[order[pos]];
+            uint32_t lo = k0 > kMargin ? k0 - kMargin : 0;
+            lo &= ~7u;
+            const uint32_t kmax = lo + kWin - kMargin - 1;
+            uint32_t end = pos + 1;
+            while (end < n_rows && end - pos < kTileRows && key[order[end]] <= kmax) ++end;
+            tile_start.push_back(pos);
+            tile_lo.push_back(lo);
+            pos = end;
+        }
+        tile_start.push_back(n_rows);
+    }
+    const uint32_t n_tiles = (uint32_t)tile_lo.size();
+    out->n_tiles = n_tiles;
+    out->tiles.assign(n_tiles, TileDesc{});
+    out->perm.assign(n_rows, 0);
+
+    // 4. pass 1 (parallel over tiles): order reads by local count, measure sizes
+    std::vector<TileSizes> sizes(n_tiles);
+    std::vector<uint32_t> cnt_tb((size_t)n_tiles * n_buckets, 0u); // remote alignments per (tile, bucket)
+    parallel_for(n_tiles, [&](uint32_t ti) {
+        const uint32_t p0 = tile_start[ti], p1 = tile_start[ti + 1];
+        const uint32_t n = p1 - p0, lo = tile_lo[ti];
+        std::vector<std::pair<uint32_t, uint32_t>> rows(n); // (local count, original read)
+        TileSizes sz;
+        uint32_t max_code = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t r = order[p0 + i];
+            uint32_t nloc = 0;
+            for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) {
+                const uint32_t c = tid[j] - lo; // wraps for tid < lo
+                if (c < kWin) { ++nloc; max_code = std::max(max_code, c); }
+                else { ++sz.remote_cnt; ++cnt_tb[(size_t)ti * n_buckets + tid[j] / kBucket]; }
+            }
+            rows[i] = {nloc, r};
+        }
+        std::stable_sort(rows.begin(), rows.end(),
+                         [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
+                             return a.first > b.first;
+                         });
+        for (uint32_t i = 0; i < n; ++i) out->perm[p0 + i] = rows[i].second;
+        sz.n_slices = (n + 63) / 64;
+        for (uint32_t s = 0; s < sz.n_slices; ++s) {
+            const uint32_t width = rows[s * 64].first; // sorted descending: first read is the longest
+            sz.w_slots += width;
+            sz.c_slots += (width + 1) / 2;
+        }
+        sz.win_len = max_code + 1;
+        sizes[ti] = sz;
+    });
+
+    // 5. offsets
+    uint64_t n_slices = 0, w_slots = 0, c_slots = 0, n_remote = 0;
+    std::vector<uint64_t> w_base(n_tiles), c_base(n_tiles);
+    for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+        TileDesc &td = out->tiles[ti];
+        td.slice_begin = (uint32_t)n_slices;
+        td.n_slices = sizes[ti].n_slices;
+        td.n_rows = tile_start[ti + 1] - tile_start[ti];
+        td.row_base = tile_start[ti];
+        td.lo = tile_lo[ti];
+        td.win_len = sizes[ti].win_len;
+        td.remote_begin = (uint32_t)n_remote;
+        td.remote_cnt = sizes[ti].remote_cnt;
+        w_base[ti] = w_slots;
+        c_base[ti] = c_slots;
+        n_slices += sizes[ti].n_slices;
+        w_slots += sizes[ti].w_slots;
+        c_slots += sizes[ti].c_slots;
+        n_remote += sizes[ti].remote_cnt;
+    }
+    if (w_slots >= (1ull << 32) || c_slots >= (1ull << 32) || n_remote >= (1ull << 32) ||
+        n_slices >= (1ull << 32)) {
+        *err = "store too large for 32-bit tile offsets";
+        return false;
+    }
+    out->n_remote = n_remote;
+    out->slices.assign(n_slices, SliceDesc{});
+    out->codes.assign(c_slots * 64, 0u);
+    if (cov_prob) out->w64.assign(w_slots * 64, 0.0);
+    else out->w32.assign(w_slots * 64, 0.0f);
+    out->r_tid.assign(n_remote, 0u);
+    if (cov_prob) out->r_w64.assign(n_remote, 0.0);
+    else out->r_w32.assign(n_remote, 0.0f);
+    out->r_row.assign(n_remote, 0);
+    out->r_slot.assign(n_remote, 0u);
+    out->q_dst.assign(n_remote, 0);
+    // bucket-major queue: slot_base(tile, b) = bucket_base[b] + remote alignments of earlier tiles in b
+    out->bucket_base.assign(n_buckets + 1, 0u);
+    {
+        uint64_t acc = 0;
+        for (uint32_t b = 0; b < n_buckets; ++b) {
+            out->bucket_base[b] = (uint32_t)acc;
+            for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+                uint32_t &c = cnt_tb[(size_t)ti * n_buckets + b];
+                const uint32_t n = c;
+                c = (uint32_t)acc; // becomes the slot base of (tile, bucket)
+                acc += n;
+            }
+        }
+        out->bucket_base[n_buckets] = (uint32_t)acc;
+    }
+
+    // 6. pass 2 (parallel over tiles): fill slices and remote records
+    std::atomic<uint64_t> n_local{0};
+    parallel_for(n_tiles, [&](uint32_t ti) {
+        const TileDesc &td = out->tiles[ti];
+        const uint32_t lo = td.lo;
+        uint64_t woff = w_base[ti], coff = c_base[ti];
+        std::vector<RemoteRec> rem;
+        rem.reserve(td.remote_cnt);
+        uint64_t nl = 0;
+        for (uint32_t s = 0; s < td.n_slices; ++s) {
+            SliceDesc &sd = out->slices[td.slice_begin + s];
+            const uint32_t row0 = s * 64;
+            const uint32_t lanes = std::min(64u, td.n_rows - row0);
+            // width = local count of the first (longest) read
+            uint32_t width = 0;
+            {
+                const uint32_t r = out->perm[td.row_base + row0];
+                for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
+                    if (tid[j] - lo < kWin) ++width;
+            }
+            sd.w_off = (uint32_t)woff;
+            sd.c_off = (uint32_t)coff;
+            sd.width = width;
+            for (uint32_t lane = 0; lane < lanes; ++lane) {
+                const uint32_t rl = row0 + lane;
+                const uint32_t r = out->perm[td.row_base + rl];
+                uint32_t jl = 0;
+                for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) {
+                    const uint32_t c = tid[j] - lo;
+                    if (c < kWin) {
+                        const uint64_t wi = (woff + jl) * 64 + lane;
+                        if (cov_prob) out->w64[wi] = (double)as_prob[j] * cov_prob[j];
+                        else out->w32[wi] = as_prob[j];
+                        out->codes[(coff + jl / 2) * 64 + lane] |= c << (16 * (jl & 1));
+                        ++jl;
+                    } else {
+                        rem.push_back(RemoteRec{tid[j], (uint16_t)rl, j});
+                    }
+                }
+                nl += jl;
+            }
+            woff += width;
+            coff += (width + 1) / 2;
+        }
+        n_local.fetch_add(nl);
+        // remote records ordered by destination bucket (then transcript)
+        std::sort(rem.begin(), rem.end(), [](const RemoteRec &a, const RemoteRec &b) {
+            return a.tid != b.tid ? a.tid < b.tid : a.j < b.j;
+        });
+        uint32_t cur_b = 0xffffffffu, slot = 0;
+        for (uint32_t i = 0; i < rem.size(); ++i) {
+            const uint64_t o = (uint64_t)td.remote_begin + i, j = rem[i].j;
+            const uint32_t b = rem[i].tid / kBucket;
+            if (b != cur_b) { cur_b = b; slot = cnt_tb[(size_t)ti * n_buckets + b]; }
+            out->r_tid[o] = rem[i].tid;
+            if (cov_prob) out->r_w64[o] = (double)as_prob[j] * cov_prob[j];
+            else out->r_w32[o] = as_prob[j];
+            out->r_row[o] = rem[i].row;
+            out->r_slot[o] = slot;
+            out->q_dst[slot] = (uint16_t)(rem[i].tid % kBucket);
+            ++slot;
+        }
+    });
+    out->n_local = n_local.load();
+    return true;
+}
+
+} // namespace oem

@@ -1,0 +1,81 @@
+"""CPU test of the tiled HBM layout (oarfish_amd/csrc/oem_layout.cpp): the product's
+layout pass is compiled into a test helper that replays the tile kernels'
+arithmetic on the host; the result must equal the oracle's m_step."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oarfish_amd import synth
+from oracle import c_oracle
+from tests.common import golden_names, load_golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "native", "layout_emul.cpp")
+LIB = os.path.join(HERE, "native", "liblayout_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    dep = os.path.join(HERE, "..", "oarfish_amd", "csrc", "oem_layout.cpp")
+    hdr = os.path.join(HERE, "..", "oarfish_amd", "csrc", "oem_layout.h")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, (SRC, dep, hdr))):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", LIB, SRC])
+    return C.CDLL(LIB)
+
+
+def _run(emul, row_ptr, tid, p, cov, T, theta, row_w=None):
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    tid = np.ascontiguousarray(tid, dtype=np.uint32)
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    cnt = np.zeros(T, dtype=np.float64)
+    stats = np.zeros(5, dtype=np.uint64)
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    rc = emul.layout_emul_m_step(vp(row_ptr), vp(tid), vp(p), vp(cov), C.c_uint64(len(row_ptr) - 1),
+                                 C.c_uint64(len(tid)), C.c_uint32(T), vp(theta), vp(row_w), vp(cnt), vp(stats))
+    assert rc == 0, f"layout self-check failed with code {rc}"
+    return cnt, stats
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_layout_on_golden(emul, name):
+    g = load_golden(name)
+    T = g["n_txps"]
+    rng = np.random.default_rng(3)
+    theta = rng.lognormal(0, 1.5, size=T)
+    theta[rng.random(T) < 0.1] = 0.0
+    o = c_oracle.Store(g["row_ptr"], g["tid"], g["as_prob"], g["cov_prob"], T)
+    got, _ = _run(emul, g["row_ptr"], g["tid"], g["as_prob"], g["cov_prob"], T, theta)
+    np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("coverage", [False, True])
+def test_layout_large_window_overflow(emul, coverage):
+    """T far beyond one window and one bucket: local + remote + several buckets."""
+    st = synth.make_store(120_000, 30_000, seed=17, coverage=coverage, threads=2)
+    rng = np.random.default_rng(4)
+    theta = rng.lognormal(0, 2, size=st.n_txps)
+    w = rng.poisson(1.0, st.n_reads).astype(np.uint32)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    got, stats = _run(emul, st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, theta)
+    np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-10, atol=1e-10)
+    got_w, _ = _run(emul, st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, theta, w)
+    np.testing.assert_allclose(got_w, c_oracle.m_step(o, theta, row_w=w), rtol=1e-10, atol=1e-10)
+    n_tiles, n_local, n_remote, n_rows, w_slots = (int(x) for x in stats)
+    assert n_local + n_remote == st.nnz and n_rows == st.n_reads
+    assert n_remote < 0.3 * st.nnz            # ~17.5 % of the alignments are uniform-random targets
+    assert w_slots < 1.15 * n_local           # SELL padding stays small
+
+
+def test_layout_empty_rows_and_sparse_keys(emul):
+    # empty reads are skipped; primaries far apart force many narrow tiles
+    rp = np.array([0, 0, 2, 2, 3, 5, 5], dtype=np.uint64)
+    tid = np.array([0, 49_999, 25_000, 7, 40_000], dtype=np.uint32)
+    p = np.array([1.0, 0.5, 1.0, 0.3, 1.0], dtype=np.float32)
+    theta = np.linspace(0.5, 2.0, 50_000)
+    o = c_oracle.Store(rp, tid, p, None, 50_000)
+    got, stats = _run(emul, rp, tid, p, None, 50_000, theta)
+    np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-12, atol=1e-14)
+    assert int(stats[3]) == 3
