@@ -196,7 +196,7 @@ void free_store(oem_store *s)
     hipFree(s->csr.w64);
     {
         oem::DeviceTiled &t = s->tiled;
-        hipFree(t.tiles); hipFree(t.slices); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
+        hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
         hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
         hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.queue);
         hipFree(t.row_w_perm);
@@ -228,7 +228,6 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     t.n_local = h.n_local;
     t.n_remote = h.n_remote;
     OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
-    OEM_TRY(upload_vec(&t.slices, h.slices, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.perm, h.perm, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.codes, h.codes, &s->hbm_bytes));
     if (s->csr.w_is_f64) {

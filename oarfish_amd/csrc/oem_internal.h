@@ -88,7 +88,6 @@ struct DeviceTiled {
     uint64_t n_local = 0;
     uint64_t n_remote = 0;
     TileDesc *tiles = nullptr;
-    SliceDesc *slices = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *codes = nullptr;
     float *w32 = nullptr;

@@ -115,6 +115,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     // 3. tile boundaries: <= kTileRows reads, primaries within the window
     std::vector<uint32_t> tile_start; // positions in `order`
     std::vector<uint32_t> tile_lo;
+    std::vector<uint32_t> tile_win; // window length: anchors + kMargin on both sides, never the full kWin by default
     {
         uint32_t pos = 0;
         while (pos < n_rows) {
@@ -126,6 +127,13 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             while (end < n_rows && end - pos < kTileRows && key[order[end]] <= kmax) ++end;
             tile_start.push_back(pos);
             tile_lo.push_back(lo);
+            // A stray alignment that merely happens to fall inside [lo, lo + kWin) is cheaper as a
+            // remote record than as a reason to load, clear and flush a whole 2048-entry window.
+            const uint32_t kend = key[order[end - 1]];
+            uint32_t win = kend - lo + kMargin + 1;
+            if (win > kWin) win = kWin;
+            if (lo + win > n_txps) win = n_txps - lo;
+            tile_win.push_back(win);
             pos = end;
         }
         tile_start.push_back(n_rows);
@@ -137,11 +145,14 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
 
     // 4. pass 1 (parallel over tiles): order reads by local count, measure sizes
     std::vector<TileSizes> sizes(n_tiles);
+    std::atomic<bool> too_wide{false};
     std::vector<uint32_t> cnt_tb((size_t)n_tiles * n_buckets, 0u); // remote alignments per (tile, bucket)
     parallel_for(n_tiles, [&](uint32_t ti) {
         const uint32_t p0 = tile_start[ti], p1 = tile_start[ti + 1];
-        const uint32_t n = p1 - p0, lo = tile_lo[ti];
-        std::vector<std::pair<uint32_t, uint32_t>> rows(n); // (local count, original read)
+        const uint32_t n = p1 - p0, lo = tile_lo[ti], win = tile_win[ti];
+        // (local count, anchor, rank among the reads with the same count and anchor, original read)
+        struct RowKey { uint32_t nloc, anchor, rank, r; };
+        std::vector<RowKey> rows(n);
         TileSizes sz;
         uint32_t max_code = 0;
         for (uint32_t i = 0; i < n; ++i) {
@@ -149,56 +160,68 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             uint32_t nloc = 0;
             for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) {
                 const uint32_t c = tid[j] - lo; // wraps for tid < lo
-                if (c < kWin) { ++nloc; max_code = std::max(max_code, c); }
+                if (c < win) { ++nloc; max_code = std::max(max_code, c); }
                 else { ++sz.remote_cnt; ++cnt_tb[(size_t)ti * n_buckets + tid[j] / kBucket]; }
             }
-            rows[i] = {nloc, r};
+            rows[i] = {nloc, key[r], 0, r};
         }
-        std::stable_sort(rows.begin(), rows.end(),
-                         [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
-                             return a.first > b.first;
-                         });
-        for (uint32_t i = 0; i < n; ++i) out->perm[p0 + i] = rows[i].second;
+        // Slices want reads of equal length (SELL padding); within one length, reads with
+        // the same anchor are dealt round-robin so that the 64 lanes of a wavefront add
+        // into different window entries (same-address LDS atomics serialise).
+        std::stable_sort(rows.begin(), rows.end(), [](const RowKey &a, const RowKey &b) {
+            return a.nloc != b.nloc ? a.nloc > b.nloc : a.anchor < b.anchor;
+        });
+        for (uint32_t i = 1; i < n; ++i)
+            if (rows[i].nloc == rows[i - 1].nloc && rows[i].anchor == rows[i - 1].anchor)
+                rows[i].rank = rows[i - 1].rank + 1;
+        std::stable_sort(rows.begin(), rows.end(), [](const RowKey &a, const RowKey &b) {
+            return a.nloc != b.nloc ? a.nloc > b.nloc : a.rank < b.rank;
+        });
+        for (uint32_t i = 0; i < n; ++i) out->perm[p0 + i] = rows[i].r;
         sz.n_slices = (n + 63) / 64;
         for (uint32_t s = 0; s < sz.n_slices; ++s) {
-            const uint32_t width = rows[s * 64].first; // sorted descending: first read is the longest
+            const uint32_t width = rows[s * 64].nloc; // sorted descending: first read is the longest
             sz.w_slots += width;
             sz.c_slots += (width + 1) / 2;
         }
         sz.win_len = max_code + 1;
+        if (rows[0].nloc > 255) too_wide.store(true);
         sizes[ti] = sz;
     });
 
+    if (too_wide.load()) {
+        *err = "a read has more than 255 alignments inside one tile window";
+        return false;
+    }
     // 5. offsets
-    uint64_t n_slices = 0, w_slots = 0, c_slots = 0, n_remote = 0;
+    uint64_t w_slots = 0, c_slots = 0, n_remote = 0;
     std::vector<uint64_t> w_base(n_tiles), c_base(n_tiles);
     for (uint32_t ti = 0; ti < n_tiles; ++ti) {
         TileDesc &td = out->tiles[ti];
-        td.slice_begin = (uint32_t)n_slices;
         td.n_slices = sizes[ti].n_slices;
+        td.w_base = (uint32_t)w_slots;
+        td.c_base = (uint32_t)c_slots;
         td.n_rows = tile_start[ti + 1] - tile_start[ti];
         td.row_base = tile_start[ti];
         td.lo = tile_lo[ti];
-        td.win_len = sizes[ti].win_len;
+        td.win_len = tile_win[ti];
         td.remote_begin = (uint32_t)n_remote;
         td.remote_cnt = sizes[ti].remote_cnt;
         w_base[ti] = w_slots;
         c_base[ti] = c_slots;
-        n_slices += sizes[ti].n_slices;
         w_slots += sizes[ti].w_slots;
         c_slots += sizes[ti].c_slots;
         n_remote += sizes[ti].remote_cnt;
     }
-    if (w_slots >= (1ull << 32) || c_slots >= (1ull << 32) || n_remote >= (1ull << 32) ||
-        n_slices >= (1ull << 32)) {
+    if (w_slots >= (1ull << 32) || c_slots >= (1ull << 32) || n_remote >= (1ull << 32)) {
         *err = "store too large for 32-bit tile offsets";
         return false;
     }
     out->n_remote = n_remote;
-    out->slices.assign(n_slices, SliceDesc{});
-    out->codes.assign(c_slots * 64, 0u);
-    if (cov_prob) out->w64.assign(w_slots * 64, 0.0);
-    else out->w32.assign(w_slots * 64, 0.0f);
+    // one row of slack: the pair loads of an odd-width slice touch the next row
+    out->codes.assign((c_slots + 1) * 64, 0u);
+    if (cov_prob) out->w64.assign((w_slots + 1) * 64, 0.0);
+    else out->w32.assign((w_slots + 1) * 64, 0.0f);
     out->r_tid.assign(n_remote, 0u);
     if (cov_prob) out->r_w64.assign(n_remote, 0.0);
     else out->r_w32.assign(n_remote, 0.0f);
@@ -225,13 +248,13 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     std::atomic<uint64_t> n_local{0};
     parallel_for(n_tiles, [&](uint32_t ti) {
         const TileDesc &td = out->tiles[ti];
-        const uint32_t lo = td.lo;
+        const uint32_t lo = td.lo, win = td.win_len;
         uint64_t woff = w_base[ti], coff = c_base[ti];
         std::vector<RemoteRec> rem;
         rem.reserve(td.remote_cnt);
         uint64_t nl = 0;
+        TileDesc &tdw = out->tiles[ti];
         for (uint32_t s = 0; s < td.n_slices; ++s) {
-            SliceDesc &sd = out->slices[td.slice_begin + s];
             const uint32_t row0 = s * 64;
             const uint32_t lanes = std::min(64u, td.n_rows - row0);
             // width = local count of the first (longest) read
@@ -239,26 +262,43 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             {
                 const uint32_t r = out->perm[td.row_base + row0];
                 for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
-                    if (tid[j] - lo < kWin) ++width;
+                    if (tid[j] - lo < win) ++width;
             }
-            sd.w_off = (uint32_t)woff;
-            sd.c_off = (uint32_t)coff;
-            sd.width = width;
+            tdw.width[s] = (uint8_t)width;
             for (uint32_t lane = 0; lane < lanes; ++lane) {
                 const uint32_t rl = row0 + lane;
                 const uint32_t r = out->perm[td.row_base + rl];
+                // local alignments of the read: anchor first, the others by ascending transcript
+                uint64_t loc[128];
                 uint32_t jl = 0;
                 for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) {
-                    const uint32_t c = tid[j] - lo;
-                    if (c < kWin) {
-                        const uint64_t wi = (woff + jl) * 64 + lane;
-                        if (cov_prob) out->w64[wi] = (double)as_prob[j] * cov_prob[j];
-                        else out->w32[wi] = as_prob[j];
-                        out->codes[(coff + jl / 2) * 64 + lane] |= c << (16 * (jl & 1));
+                    if (tid[j] - lo < win) {
+                        if (jl < 128) loc[jl] = j;
                         ++jl;
                     } else {
                         rem.push_back(RemoteRec{tid[j], (uint16_t)rl, j});
                     }
+                }
+                std::vector<uint64_t> big;
+                uint64_t *lp = loc;
+                if (jl > 128) { // longer than --best-n allows in the reference; keep it correct anyway
+                    big.reserve(jl);
+                    for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
+                        if (tid[j] - lo < win) big.push_back(j);
+                    lp = big.data();
+                }
+                std::sort(lp, lp + jl, [&](uint64_t a, uint64_t b) {
+                    const bool aa = tid[a] == key[r], ab = tid[b] == key[r];
+                    if (aa != ab) return aa;
+                    return tid[a] != tid[b] ? tid[a] < tid[b] : a < b;
+                });
+                for (uint32_t q = 0; q < jl; ++q) {
+                    const uint64_t j = lp[q];
+                    const uint32_t c = tid[j] - lo;
+                    const uint64_t wi = (woff + q) * 64 + lane;
+                    if (cov_prob) out->w64[wi] = (double)as_prob[j] * cov_prob[j];
+                    else out->w32[wi] = as_prob[j];
+                    out->codes[(coff + q / 2) * 64 + lane] |= (c * 8u) << (16 * (q & 1)); // LDS byte offset
                 }
                 nl += jl;
             }

@@ -32,27 +32,33 @@
 namespace oem {
 
 constexpr uint32_t kTileRows = 1024;  // reads per tile (16 slices of 64)
-constexpr uint32_t kWin = 2048;       // transcripts per tile window (2 x 16 KiB of LDS)
+constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB of LDS); 8*kWin must fit 16 bits
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
 constexpr uint32_t kBucket = 8192;    // transcripts per remote bucket (64 KiB of LDS)
 
-struct TileDesc { // 32 bytes
-    uint32_t slice_begin; // first slice of the tile in the slice table
-    uint32_t n_rows;      // reads in the tile
-    uint32_t row_base;    // position of the tile's first read in the permuted order
-    uint32_t lo;          // first transcript of the window
-    uint32_t win_len;     // window entries actually used (<= kWin)
+constexpr uint32_t kTileSlices = kTileRows / 64;
+
+// Everything a workgroup needs to know about its tile, fetched with one scalar
+// load: with the slice widths in hand every wavefront derives the addresses of
+// all its slices without a dependent descriptor load.
+struct TileDesc { // 64 bytes
+    uint32_t n_rows;       // reads in the tile
+    uint32_t row_base;     // position of the tile's first read in the permuted order
+    uint32_t lo;           // first transcript of the window
+    uint32_t win_len;      // window entries actually used (<= kWin)
     uint32_t remote_begin; // first remote record of the tile
     uint32_t remote_cnt;
+    uint32_t w_base;       // weights of slice s start at (w_base + sum_{i<s} width[i]) * 64
+    uint32_t c_base;       // codes   of slice s start at (c_base + sum_{i<s} (width[i]+1)/2) * 64
+    uint8_t width[kTileSlices]; // max local alignments of the 64 reads of each slice (0 = no slice)
     uint32_t n_slices;
+    uint32_t pad[3];
 };
+static_assert(sizeof(TileDesc) == 64, "TileDesc layout");
+static_assert(kTileSlices == 16, "TileDesc::width is sized for 16 slices");
 
-struct SliceDesc { // 16 bytes
-    uint32_t w_off;  // weights:  w[(w_off + j) * 64 + lane],            j < width
-    uint32_t c_off;  // codes:    c[(c_off + j/2) * 64 + lane] >> 16*(j&1) & 0xffff
-    uint32_t width;  // max local alignments of the 64 reads
-    uint32_t pad;
-};
+// Slice data: weights w[(off + j) * 64 + lane], j < width; codes packed in pairs,
+// c[(coff + j/2) * 64 + lane] >> 16*(j&1) & 0xffff = 8 * (tid - lo) (an LDS byte offset).
 
 // Host-side result of the layout pass; all arrays are uploaded verbatim.
 struct TiledHost {
@@ -62,7 +68,6 @@ struct TiledHost {
     uint64_t n_local = 0;   // local alignments
     uint64_t n_remote = 0;  // remote alignments
     std::vector<TileDesc> tiles;
-    std::vector<SliceDesc> slices;
     std::vector<uint32_t> perm;     // permuted position -> original read index
     std::vector<uint32_t> codes;    // packed pairs of 16-bit window codes
     std::vector<float> w32;         // local weights (coverage off)

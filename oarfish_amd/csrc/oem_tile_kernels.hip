@@ -12,13 +12,14 @@
 //
 // HBM-bound by design (no MFMA: this is sparse gather/scatter).  Algorithmic
 // bytes per pass are SURVEY.md section 8d's nnz*(4+4) + (R+1)*4 + 2*T*8.
+#include <cstdlib>
+
 #include "oem_internal.h"
 
 namespace oem {
 
 namespace {
 
-constexpr int kTileThreads = 256;
 constexpr int kFoldThreads = 1024;
 
 __device__ __forceinline__ void lds_add_f64(double *p, double v)
@@ -26,82 +27,236 @@ __device__ __forceinline__ void lds_add_f64(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_f64
 }
 
-template <typename WT>
-__global__ __launch_bounds__(kTileThreads) void k_em_tile(
-    const TileDesc *__restrict__ tiles, const SliceDesc *__restrict__ slices,
-    const uint32_t *__restrict__ codes, const WT *__restrict__ w,
-    const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LDS window entries are addressed by byte offset (the 16-bit codes are stored
+// pre-multiplied by 8), which saves the shift per alignment.
+__device__ __forceinline__ double lds_ld(const double *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ double *lds_at(double *base, uint32_t byte_off)
+{
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
+// Registers of one SELL-64 slice for one lane: up to kCh local alignments
+// (longer reads spill to a reload loop); kRem = remote alignments per thread whose
+// theta*w stays in registers between the two remote phases.
+template <typename WT, int kCh>
+struct SliceRegs {
+    WT w[kCh];
+    uint32_t c[kCh / 2];
+};
+
+// Issue every load of a slice before any use.  `wbase`/`cbase`/`width` are
+// wave-uniform (SGPRs), so the loads take the scalar-base + lane-offset form with
+// immediate offsets, and the width tests are scalar branches: no per-alignment
+// address arithmetic.  Pairs are loaded together; the second element of the last
+// pair of an odd-width slice is the next slice's first alignment (the arrays are
+// padded by one row) and is zeroed.
+template <typename WT, int kCh>
+__device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__restrict__ wbase,
+                                           const uint32_t *__restrict__ cbase, uint32_t lane,
+                                           uint32_t width)
+{
+#pragma unroll
+    for (int g = 0; g < kCh / 2; ++g) {
+        if ((uint32_t)(2 * g) < width) {
+            r.w[2 * g] = wbase[(2 * g) * 64 + lane];
+            r.w[2 * g + 1] = wbase[(2 * g + 1) * 64 + lane];
+            r.c[g] = cbase[g * 64 + lane];
+        } else {
+            r.w[2 * g] = (WT)0;
+            r.w[2 * g + 1] = (WT)0;
+            r.c[g] = 0u;
+        }
+    }
+}
+
+template <typename WT, int kCh>
+__device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
+                                           uint32_t lane, const WT *__restrict__ wbase,
+                                           const uint32_t *__restrict__ cbase, const TileDesc &td,
+                                           const double *theta_l, double *cnt_l, double *den_l,
+                                           const uint32_t *__restrict__ row_w_perm, uint32_t ablate)
+{
+    const uint32_t rl = s * 64 + lane;
+    if (ablate & 16) { // timing experiment: consume the operands, nothing else
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) acc += (float)cur.w[k] + (float)cur.c[k >> 1];
+        den_l[rl] = acc;
+        return;
+    }
+    double x[kCh];
+    double denom = den_l[rl];
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) {
+        const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
+        const double wk = (uint32_t)k < width ? (double)cur.w[k] : 0.0;   // uniform select
+        x[k] = lds_ld(theta_l, off) * wk;                                  // em.rs:111
+        denom += x[k];
+    }
+    for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
+        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        denom += lds_ld(theta_l, off) * (double)wbase[j * 64 + lane];
+    }
+    double scale = 1.0;
+    if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
+    const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
+    den_l[rl] = inv;
+    if (ablate & 2) return;
+
+    // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
+    // share it, and 64 same-address LDS atomics would serialise: reduce across the
+    // wavefront and let one lane add.
+    {
+        const uint32_t off0 = cur.c[0] & 0xffffu;
+        const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
+        const double v0 = x[0] * inv;
+        if (__all(off0 == u)) {
+            const double sum = wave_sum_f64(v0);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u), sum);
+        } else if (v0 != 0.0) {
+            lds_add_f64(lds_at(cnt_l, off0), v0);                           // em.rs:128-129
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < kCh; ++k) {
+        if ((uint32_t)k < width) { // uniform
+            const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
+            const double v = x[k] * inv;
+            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off), v);
+        }
+    }
+    for (uint32_t j = kCh; j < width; ++j) {
+        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
+        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off), v);
+    }
+}
+
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves>
+__global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
+    const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
+    const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
-    const EmState *state, const uint32_t *__restrict__ row_w_perm)
+    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate)
 {
     if (state && state->done) return;
 
     __shared__ double theta_l[kWin];
     __shared__ double cnt_l[kWin];
-    __shared__ double den_l[kTileRows]; // remote part of the denominators, then row_w/denom
+    __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
-    const TileDesc td = tiles[blockIdx.x];
+    const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
     const uint32_t tx = threadIdx.x;
+    const uint32_t lane = tx & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6); // SGPR: slice control flow is scalar
+    constexpr uint32_t kWaves = kTileThreads / 64;
+    constexpr uint32_t kPerWave = kTileSlices / kWaves; // slices per wavefront (round-robin: s = wave + kWaves*q)
 
-    for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
-        theta_l[i] = theta[td.lo + i];
-        cnt_l[i] = 0.0;
+    // addresses of this wavefront's slices, from the widths alone (scalar prefix sums)
+    uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
+    {
+        uint32_t accw = td.w_base, accc = td.c_base;
+#pragma unroll
+        for (uint32_t i = 0; i < kTileSlices; ++i) {
+            const uint32_t wi = td.width[i];
+            if ((i % kWaves) == wave) {
+                woff[i / kWaves] = accw;
+                coff[i / kWaves] = accc;
+                wid[i / kWaves] = wi;
+            }
+            accw += wi;
+            accc += (wi + 1) >> 1;
+        }
     }
-    for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
-    __syncthreads();
 
-    // remote alignments, phase A: x = theta[t]*w parked in the queue, added to the read's denominator
-    for (uint32_t i = tx; i < td.remote_cnt; i += kTileThreads) {
+    // ---- every long-latency load of the tile is issued here, before any use ---------
+    SliceRegs<WT, kCh> R[kPerWave];
+#pragma unroll
+    for (uint32_t q = 0; q < kPerWave; ++q)
+        load_slice(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+
+    double rx[kRem];      // theta[t] * w of this thread's remote alignments
+    uint32_t rrow[kRem];  // their read (index inside the tile)
+    uint32_t rslot[kRem]; // their slot in the bucket-major queue
+    {
+        uint32_t rt[kRem];
+        WT rw[kRem];
+#pragma unroll
+        for (int k = 0; k < kRem; ++k) {
+            const uint32_t i = tx + k * kTileThreads;
+            rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0;
+            if (i < td.remote_cnt && !(ablate & 1)) {
+                const uint32_t o = td.remote_begin + i;
+                rt[k] = r_tid[o];
+                rw[k] = r_w[o];
+                rrow[k] = r_row[o];
+                rslot[k] = r_slot[o];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
+    }
+    if (!(ablate & 32)) {
+        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
+            theta_l[i] = theta[td.lo + i];
+            cnt_l[i] = 0.0;
+        }
+        for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
+    }
+    if (!(ablate & 64)) __syncthreads();
+
+    // ---- remote alignments, phase A: denominators --------------------------------
+#pragma unroll
+    for (int k = 0; k < kRem; ++k)
+        if (tx + k * kTileThreads < td.remote_cnt && !(ablate & 1)) lds_add_f64(&den_l[rrow[k]], rx[k]);
+    for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) { // overflow: park in the queue
         const uint32_t o = td.remote_begin + i;
         const double x = theta[r_tid[o]] * (double)r_w[o];
         queue[r_slot[o]] = x;
         lds_add_f64(&den_l[r_row[o]], x);
     }
-    __syncthreads();
+    if (!(ablate & 64)) __syncthreads();
 
-    // local alignments: one read per lane, one slice per wavefront at a time
-    const uint32_t lane = tx & 63u, wave = tx >> 6;
-    for (uint32_t s = wave; s < td.n_slices; s += kTileThreads / 64) {
-        const SliceDesc sd = slices[td.slice_begin + s];
-        const uint32_t rl = s * 64 + lane;
-        const WT *wp = w + (size_t)sd.w_off * 64 + lane;
-        const uint32_t *cp = codes + (size_t)sd.c_off * 64 + lane;
-        double denom = den_l[rl];
-        for (uint32_t j = 0; j < sd.width; j += 2) {
-            const uint32_t cc = cp[(size_t)(j >> 1) * 64];
-            denom += theta_l[cc & 0xffffu] * (double)wp[(size_t)j * 64];           // em.rs:111
-            if (j + 1 < sd.width) denom += theta_l[cc >> 16] * (double)wp[(size_t)(j + 1) * 64];
-        }
-        double scale = 1.0;
-        if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
-        const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;      // em.rs:115
-        den_l[rl] = inv;
-        if (inv != 0.0) {
-            for (uint32_t j = 0; j < sd.width; j += 2) {
-                const uint32_t cc = cp[(size_t)(j >> 1) * 64];
-                const double w0 = (double)wp[(size_t)j * 64];
-                if (w0 != 0.0) lds_add_f64(&cnt_l[cc & 0xffffu], theta_l[cc & 0xffffu] * w0 * inv); // em.rs:128-129
-                if (j + 1 < sd.width) {
-                    const double w1 = (double)wp[(size_t)(j + 1) * 64];
-                    if (w1 != 0.0) lds_add_f64(&cnt_l[cc >> 16], theta_l[cc >> 16] * w1 * inv);
-                }
-            }
-        }
+    // ---- local alignments: one read per lane, all operands already in registers -----
+#pragma unroll
+    for (uint32_t q = 0; q < kPerWave; ++q) {
+        const uint32_t s = wave + kWaves * q;
+        if (s < td.n_slices)
+            fold_slice(R[q], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+                       theta_l, cnt_l, den_l, row_w_perm, ablate);
     }
-    __syncthreads();
+    if (!(ablate & 64)) __syncthreads();
 
-    // remote alignments, phase B: queue <- x * (c_i / denom_i)
-    for (uint32_t i = tx; i < td.remote_cnt; i += kTileThreads) {
+    // ---- remote alignments, phase B: queue <- x * (c_i / denom_i) ------------------
+#pragma unroll
+    for (int k = 0; k < kRem; ++k) {
+        const uint32_t i = tx + k * kTileThreads;
+        if (i < td.remote_cnt && !(ablate & 9)) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
+    }
+    for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
         const uint32_t q = r_slot[o];
         queue[q] = queue[q] * den_l[r_row[o]];
     }
 
-    // flush the window: consecutive lanes -> consecutive addresses (coalesced atomics)
+    // ---- flush the window: consecutive lanes -> consecutive addresses ---------------
+    if (ablate & 32) return;
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         const double v = cnt_l[i];
-        if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
+        if (v != 0.0 && !(ablate & 4)) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
 }
 
@@ -120,7 +275,21 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     if (s0 == s1) return;
     for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreads) acc[i] = 0.0;
     __syncthreads();
-    for (uint32_t o = s0 + threadIdx.x; o < s1; o += kFoldThreads) {
+    // four independent loads in flight per thread before the LDS atomics
+    uint32_t o = s0 + threadIdx.x;
+    for (; o + 3 * kFoldThreads < s1; o += 4 * kFoldThreads) {
+        double v[4];
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = queue[o + k * kFoldThreads];
+            d[k] = q_dst[o + k * kFoldThreads];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (v[k] != 0.0) lds_add_f64(&acc[d[k]], v[k]);
+    }
+    for (; o < s1; o += kFoldThreads) {
         const double v = queue[o];
         if (v != 0.0) lds_add_f64(&acc[q_dst[o]], v);
     }
@@ -143,26 +312,62 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 
 } // namespace
 
+template <typename WT>
+static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT *r_w,
+                                const double *theta, double *cnt, const EmState *state,
+                                const uint32_t *row_w_perm)
+{
+    const DeviceTiled &t = s->tiled;
+    static const uint32_t ablate = [] {
+        const char *e = getenv("OEM_TILE_ABLATE"); // timing experiments only: results are wrong when set
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+#define OEM_TILE(CH, REM, TH, MW)                                                                  \
+    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW>), dim3(t.n_tiles), dim3(TH), 0,              \
+                       s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot,             \
+                       t.queue, theta, cnt, state, row_w_perm, ablate)
+    switch (variant) {
+    case 1: OEM_TILE(8, 6, 256, 4); break;
+    case 2: OEM_TILE(8, 6, 256, 3); break;
+    case 3: OEM_TILE(12, 3, 512, 2); break;
+    case 4: OEM_TILE(8, 3, 512, 2); break;
+    case 5: OEM_TILE(8, 3, 512, 3); break;
+    case 6: OEM_TILE(12, 2, 1024, 2); break;
+    case 7: OEM_TILE(8, 2, 1024, 2); break;
+    case 8: OEM_TILE(8, 3, 512, 6); break;
+    case 9: OEM_TILE(8, 2, 512, 6); break;
+    case 10: OEM_TILE(6, 3, 512, 6); break;
+    case 11: OEM_TILE(8, 3, 512, 8); break;
+    case 12: OEM_TILE(6, 2, 1024, 4); break;
+    default: OEM_TILE(12, 3, 512, 3); break;
+    }
+#undef OEM_TILE
+}
+
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    if (s->csr.w_is_f64) {
-        hipLaunchKernelGGL((k_em_tile<double>), dim3(t.n_tiles), dim3(kTileThreads), 0, s->stream,
-                           t.tiles, t.slices, t.codes, (const double *)t.w64, t.r_tid,
-                           (const double *)t.r_w64, t.r_row, t.r_slot, t.queue, theta, cnt, state,
-                           row_w_perm);
-    } else {
-        hipLaunchKernelGGL((k_em_tile<float>), dim3(t.n_tiles), dim3(kTileThreads), 0, s->stream,
-                           t.tiles, t.slices, t.codes, (const float *)t.w32, t.r_tid,
-                           (const float *)t.r_w32, t.r_row, t.r_slot, t.queue, theta, cnt, state,
-                           row_w_perm);
-    }
+    static const int variant = [] {
+        const char *e = getenv("OEM_TILE_VARIANT"); // tuning knob (register blocking of k_em_tile)
+        return e ? atoi(e) : 0;
+    }();
+    if (s->csr.w_is_f64)
+        launch_tile_variant<double>(variant, s, (const double *)t.w64, (const double *)t.r_w64, theta,
+                                    cnt, state, row_w_perm);
+    else
+        launch_tile_variant<float>(variant, s, (const float *)t.w32, (const float *)t.r_w32, theta, cnt,
+                                   state, row_w_perm);
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
-        // ~2 workgroups of 1024 threads per CU in total, split over the buckets by queue length
-        uint32_t n_groups = 512 / (t.n_buckets ? t.n_buckets : 1);
+        // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
+        // fewer, longer-running workgroups mean fewer flush atomics)
+        static const uint32_t fold_wgs = [] {
+            const char *e = getenv("OEM_FOLD_WGS"); // tuning knob
+            return e ? (uint32_t)atoi(e) : 256u;
+        }();
+        uint32_t n_groups = fold_wgs / (t.n_buckets ? t.n_buckets : 1);
         const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
         const uint32_t max_useful = (uint32_t)((per_bucket + 4095) / 4096);
         if (n_groups > max_useful) n_groups = max_useful;

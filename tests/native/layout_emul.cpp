@@ -41,14 +41,17 @@ extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, 
             if (h.r_row[o] >= td.n_rows) return 6;
             den_l[h.r_row[o]] += x;
         }
+        uint32_t w_off = td.w_base, c_off = td.c_base;
         for (uint32_t s = 0; s < td.n_slices; ++s) {
-            const SliceDesc &sd = h.slices[td.slice_begin + s];
+            struct { uint32_t w_off, c_off, width; } sd = {w_off, c_off, td.width[s]};
+            w_off += sd.width;
+            c_off += (sd.width + 1) / 2;
             for (uint32_t lane = 0; lane < 64; ++lane) {
                 const uint32_t rl = s * 64 + lane;
                 double denom = den_l[rl];
                 for (uint32_t j = 0; j < sd.width; ++j) {
                     const uint32_t cc = h.codes[((size_t)sd.c_off + j / 2) * 64 + lane];
-                    const uint32_t c = (cc >> (16 * (j & 1))) & 0xffffu;
+                    const uint32_t c = ((cc >> (16 * (j & 1))) & 0xffffu) / 8u;
                     const size_t wi = ((size_t)sd.w_off + j) * 64 + lane;
                     const double w = f64 ? h.w64[wi] : (double)h.w32[wi];
                     if (c >= td.win_len) return 7;
@@ -61,7 +64,7 @@ extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, 
                 if (inv != 0.0)
                     for (uint32_t j = 0; j < sd.width; ++j) {
                         const uint32_t cc = h.codes[((size_t)sd.c_off + j / 2) * 64 + lane];
-                        const uint32_t c = (cc >> (16 * (j & 1))) & 0xffffu;
+                        const uint32_t c = ((cc >> (16 * (j & 1))) & 0xffffu) / 8u;
                         const size_t wi = ((size_t)sd.w_off + j) * 64 + lane;
                         const double w = f64 ? h.w64[wi] : (double)h.w32[wi];
                         if (w != 0.0) cnt_l[c] += theta_l[c] * w * inv;
@@ -84,7 +87,7 @@ extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, 
         }
     if (stats) {
         stats[0] = h.n_tiles; stats[1] = h.n_local; stats[2] = h.n_remote; stats[3] = h.n_rows;
-        stats[4] = (f64 ? h.w64.size() : h.w32.size());
+        stats[4] = (f64 ? h.w64.size() : h.w32.size()) - 64;
     }
     return 0;
 }
