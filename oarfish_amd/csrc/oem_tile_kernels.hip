@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
     }
 }
 
-template <typename WT, int kCh>
+template <typename WT, int kCh, int kCopies>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
@@ -114,6 +114,11 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     den_l[rl] = inv;
     if (ablate & 2) return;
 
+    // The count window is kept in kCopies interleaved copies (entry c of copy p at
+    // (c * kCopies + p) * 8): lanes of different copies that add into the same
+    // transcript hit different addresses (and adjacent banks), which divides the
+    // same-address serialisation of the LDS atomics by up to kCopies.
+    const uint32_t copy_off = (lane % kCopies) * 8u;
     // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
     // share it, and 64 same-address LDS atomics would serialise: reduce across the
     // wavefront and let one lane add.
@@ -123,9 +128,9 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
             const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u), sum);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
         } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, off0), v0);                           // em.rs:128-129
+            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
         }
     }
 #pragma unroll
@@ -133,18 +138,18 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
             const double v = x[k] * inv;
-            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off), v);
+            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
         const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
-        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off), v);
+        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kUpfront>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     if (state && state->done) return;
 
     __shared__ double theta_l[kWin];
-    __shared__ double cnt_l[kWin];
+    __shared__ double cnt_l[kWin * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
@@ -183,9 +188,12 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
 
     // ---- every long-latency load of the tile is issued here, before any use ---------
-    SliceRegs<WT, kCh> R[kPerWave];
+    // kUpfront: all slices of the wavefront are loaded here; otherwise the first one is, and
+    // the rest are prefetched one slice ahead of the fold (two register sets, ping-pong).
+    constexpr uint32_t kSets = kUpfront ? kPerWave : (kPerWave > 1 ? 2 : 1);
+    SliceRegs<WT, kCh> R[kSets];
 #pragma unroll
-    for (uint32_t q = 0; q < kPerWave; ++q)
+    for (uint32_t q = 0; q < (kUpfront ? kPerWave : 1u); ++q)
         load_slice(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
@@ -210,10 +218,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
     }
     if (!(ablate & 32)) {
-        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
-            theta_l[i] = theta[td.lo + i];
-            cnt_l[i] = 0.0;
-        }
+        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) theta_l[i] = theta[td.lo + i];
+        for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
         for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     }
     if (!(ablate & 64)) __syncthreads();
@@ -234,8 +240,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
     for (uint32_t q = 0; q < kPerWave; ++q) {
         const uint32_t s = wave + kWaves * q;
+        if (!kUpfront && q + 1 < kPerWave)
+            load_slice(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+                       wid[q + 1]);
         if (s < td.n_slices)
-            fold_slice(R[q], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+            fold_slice<WT, kCh, kCopies>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
                        theta_l, cnt_l, den_l, row_w_perm, ablate);
     }
     if (!(ablate & 64)) __syncthreads();
@@ -255,7 +264,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // ---- flush the window: consecutive lanes -> consecutive addresses ---------------
     if (ablate & 32) return;
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
-        const double v = cnt_l[i];
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
         if (v != 0.0 && !(ablate & 4)) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
 }
@@ -322,24 +333,16 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
         const char *e = getenv("OEM_TILE_ABLATE"); // timing experiments only: results are wrong when set
         return e ? (uint32_t)atoi(e) : 0u;
     }();
-#define OEM_TILE(CH, REM, TH, MW)                                                                  \
-    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW>), dim3(t.n_tiles), dim3(TH), 0,              \
+#define OEM_TILE(CH, REM, TH, MW, NC, UP)                                                          \
+    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP>), dim3(t.n_tiles), dim3(TH), 0,      \
                        s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot,             \
                        t.queue, theta, cnt, state, row_w_perm, ablate)
     switch (variant) {
-    case 1: OEM_TILE(8, 6, 256, 4); break;
-    case 2: OEM_TILE(8, 6, 256, 3); break;
-    case 3: OEM_TILE(12, 3, 512, 2); break;
-    case 4: OEM_TILE(8, 3, 512, 2); break;
-    case 5: OEM_TILE(8, 3, 512, 3); break;
-    case 6: OEM_TILE(12, 2, 1024, 2); break;
-    case 7: OEM_TILE(8, 2, 1024, 2); break;
-    case 8: OEM_TILE(8, 3, 512, 6); break;
-    case 9: OEM_TILE(8, 2, 512, 6); break;
-    case 10: OEM_TILE(6, 3, 512, 6); break;
-    case 11: OEM_TILE(8, 3, 512, 8); break;
-    case 12: OEM_TILE(6, 2, 1024, 4); break;
-    default: OEM_TILE(12, 3, 512, 3); break;
+    case 1: OEM_TILE(8, 3, 512, 2, 4, true); break;   // all slices up front, 8 waves
+    case 2: OEM_TILE(12, 6, 256, 2, 4, false); break;
+    case 3: OEM_TILE(8, 3, 512, 2, 4, false); break;
+    case 4: OEM_TILE(8, 6, 256, 5, 4, false); break;
+    default: OEM_TILE(8, 6, 256, 2, 4, false); break; // 4 waves, 4 slices each, one slice prefetched ahead
     }
 #undef OEM_TILE
 }
