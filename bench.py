@@ -179,9 +179,18 @@ def main():
     hbm_bytes, alg_bytes = store.bytes()
     k_ms = store.time_m_step(50)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # HBM bytes of one pass from the rocprofv3 PMC passes of this same command (collected by
+    # scripts/collect_profiles.sh, FETCH_SIZE corrected by the calibration recorded beside it)
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", f"r01_{args.workload}_hbm_traffic.json")
+    if world == 1 and os.path.exists(tj):
+        t = json.load(open(tj))["per_launch_bytes"]
+        traffic = sum(t[k]["read"] + t[k]["write"] for k in ("k_em_tile", "k_remote_fold") if k in t)
+        traffic_src = os.path.relpath(tj, ROOT)
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, kernel="k_em_pass",
-                    kernel_avg_ms=k_ms, algorithmic_bytes_per_launch=alg_bytes)
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                    kernel="k_em_tile + k_remote_fold (one E/M pass)", kernel_avg_ms=k_ms,
+                    algorithmic_bytes_per_launch=alg_bytes, traffic_source=traffic_src)
 
     # bootstraps/sec (each = one resampled EM to convergence, em.rs:273-290)
     boots = None

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             }
         }
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
+        for (int k = 0; k < kRem; ++k) rx[k] = theta[(ablate & 128) ? (rt[k] & 7u) : rt[k]] * (double)rw[k];
     }
     if (!(ablate & 32)) {
         for (uint32_t i = tx; i < td.win_len; i += kTileThreads) theta_l[i] = theta[td.lo + i];
