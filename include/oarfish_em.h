@@ -93,6 +93,14 @@ int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, const float *
                      int device, const oem_store_opts *opts, oem_store **out);
 void oem_store_destroy(oem_store *store);
 
+/* Tuning switches of a store (not part of the reference's semantics; results are
+ * unchanged up to floating-point summation order). */
+typedef enum {
+    OEM_OPT_BATCH_BOOTSTRAP = 1 /* value 1: oem_bootstrap runs 4 replicates per pass over the matrix
+                                   (default 0: one replicate per pass, currently the faster form) */
+} oem_option;
+int oem_store_set_option(oem_store *store, uint32_t option, uint64_t value);
+
 /* store.len() / num_aligned_reads() (oarfish_types.rs:562-564,746-748),
  * total_len() (:741-743), txp_info.len(). */
 int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uint32_t *n_txps);

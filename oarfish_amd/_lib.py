@@ -20,11 +20,12 @@ OEM_ERR_RCCL = 4
 OEM_ERR_NO_DEVICE = 5
 OEM_ERR_STATE = 6
 OEM_UNIQUE_ID_BYTES = 128
+OEM_OPT_BATCH_BOOTSTRAP = 1
 
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "oem_abi_version", "oem_last_error", "oem_device_count",
-    "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes",
+    "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_set_option",
     "oem_m_step", "oem_em_run",
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
@@ -80,6 +81,7 @@ def lib() -> C.CDLL:
     L.oem_store_destroy.restype = None
     L.oem_store_dims.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.oem_store_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.oem_store_set_option.argtypes = [vp, u32, u64]
     L.oem_m_step.argtypes = [vp, vp, vp, vp]
     L.oem_em_run.argtypes = [vp, vp, u32, f64, u32, vp, C.POINTER(RunInfoC)]
     L.oem_bootstrap_weights.argtypes = [vp, u64, u32, vp]

@@ -7,6 +7,7 @@
 //   single_cell.rs:139-160  per-cell em::em    -> oem_em_run_cells
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -185,6 +186,112 @@ int ensure_row_w(oem_store *s)
     return OEM_OK;
 }
 
+int ensure_batch(oem_store *s)
+{
+    BatchBuffers &b = s->batch;
+    if (b.theta) return OEM_OK;
+    const size_t T = s->csr.n_txps;
+    OEM_TRY(dev_alloc(&b.theta, T * kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.cnt, 2 * T * kBatch, &s->hbm_bytes));
+    b.cnt2 = b.cnt + T * kBatch;
+    OEM_TRY(dev_alloc(&b.out, T * kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.queue, (size_t)s->tiled.n_remote * kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 4, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.row_w_all, (size_t)s->csr.n_reads * kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.overflow, 1, &s->hbm_bytes));
+    OEM_HIP(hipHostMalloc((void **)&b.h_state, sizeof(BatchState) * kBatch, hipHostMallocDefault));
+    OEM_HIP(hipHostMalloc((void **)&b.h_out, sizeof(double) * T * kBatch, hipHostMallocDefault));
+    return OEM_OK;
+}
+
+bool can_batch(const oem_store *s)
+{
+    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0;
+}
+
+// nb (2..kBatch) bootstrap replicates, first global replica index b0, sharing every pass
+// over the matrix.  Returns OEM_OK and *fell_back = true (nothing written) if a multiplicity
+// does not fit a byte; the caller then runs these replicates one per pass.
+int run_bootstrap_batch(oem_store *s, uint32_t b0, uint32_t nb, uint64_t seed, const uint32_t *row_w_all,
+                        const double *init, uint32_t max_iter, double conv_thresh, double *out,
+                        oem_run_info *infos, bool *fell_back)
+{
+    *fell_back = false;
+    OEM_TRY(ensure_batch(s));
+    BatchBuffers &bb = s->batch;
+    const uint32_t T = s->csr.n_txps;
+    const uint64_t R = s->csr.n_reads;
+    // resamples: injected, or drawn on the device (em.rs:274-276)
+    for (uint32_t k = 0; k < (uint32_t)kBatch; ++k) {
+        uint32_t *dst = bb.row_w_all + (size_t)k * R;
+        if (k >= nb) {
+            OEM_HIP(hipMemsetAsync(dst, 0, sizeof(uint32_t) * R, s->stream));
+        } else if (row_w_all) {
+            OEM_HIP(hipMemcpyAsync(dst, row_w_all + (size_t)(b0 + k) * R, sizeof(uint32_t) * R,
+                                   hipMemcpyHostToDevice, s->stream));
+        } else {
+            OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed, b0 + k));
+        }
+    }
+    OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
+    OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
+    uint32_t h_overflow = 0;
+    OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    if (h_overflow) {
+        *fell_back = true;
+        return OEM_OK;
+    }
+    // theta init (em.rs:160-167; total_weight is the store's read count also for a replicate, em.rs:154)
+    const double *d_init = nullptr;
+    if (init) {
+        OEM_HIP(hipMemcpyAsync(s->theta, init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+        d_init = s->theta;
+    }
+    OEM_TRY(launch_batch_init_theta(s, bb, d_init, (double)s->global_n_reads / (double)T));
+    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
+    for (uint32_t k = 0; k < (uint32_t)kBatch; ++k) {
+        BatchState &st = bb.h_state[k];
+        std::memset(&st, 0, sizeof(st));
+        st.phase = k < nb ? (max_iter == 0 ? kPhaseFinal : kPhaseRunning) : kPhaseFinished;
+    }
+    OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
+    EmParams p{T, max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, conv_thresh};
+    if (max_iter == 0) return fail(OEM_ERR_ARG, "batched bootstrap needs max_iter >= 1");
+    const bool sharded = s->comm && comm_size(s->comm) > 1;
+    uint32_t launched = 0;
+    const uint32_t total = max_iter + 1; // loop passes + the final one
+    while (launched < total) {
+        uint32_t chunk = launched == 0 ? 52 : 16;
+        if (chunk > total - launched) chunk = total - launched;
+        for (uint32_t k = 0; k < chunk; ++k) {
+            OEM_TRY(launch_batch_pass(s, bb));
+            if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, 2 * (size_t)T * kBatch, s->stream));
+            OEM_TRY(launch_batch_reldiff(s, bb, p));
+        }
+        launched += chunk;
+        OEM_HIP(hipMemcpyAsync(bb.h_state, bb.state, sizeof(BatchState) * kBatch, hipMemcpyDeviceToHost, s->stream));
+        OEM_HIP(hipStreamSynchronize(s->stream));
+        bool all = true;
+        for (int k = 0; k < kBatch; ++k) all = all && bb.h_state[k].phase == kPhaseFinished;
+        if (all) break;
+    }
+    OEM_HIP(hipMemcpyAsync(bb.h_out, bb.out, sizeof(double) * T * kBatch, hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    for (uint32_t k = 0; k < nb; ++k) {
+        std::memcpy(out + (size_t)(b0 + k) * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
+        if (infos) {
+            infos[b0 + k].niter = bb.h_state[k].niter;
+            infos[b0 + k].n_passes = bb.h_state[k].n_passes;
+            infos[b0 + k].converged = bb.h_state[k].converged;
+            infos[b0 + k].reserved = 0;
+            infos[b0 + k].rel_diff = bb.h_state[k].last_rel;
+        }
+    }
+    return OEM_OK;
+}
+
 void free_store(oem_store *s)
 {
     if (!s) return;
@@ -200,6 +307,13 @@ void free_store(oem_store *s)
         hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
         hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.queue);
         hipFree(t.row_w_perm);
+    }
+    {
+        oem::BatchBuffers &b = s->batch;
+        hipFree(b.theta); hipFree(b.cnt); hipFree(b.out); hipFree(b.queue); hipFree(b.state);
+        hipFree(b.row_w); hipFree(b.row_w_all); hipFree(b.overflow);
+        if (b.h_state) hipHostFree(b.h_state);
+        if (b.h_out) hipHostFree(b.h_out);
     }
     hipFree(s->theta);
     hipFree(s->cnt);
@@ -369,6 +483,16 @@ extern "C" int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_
     return OEM_OK;
 }
 
+extern "C" int oem_store_set_option(oem_store *store, uint32_t option, uint64_t value)
+{
+    if (!store) return fail(OEM_ERR_ARG, "oem_store_set_option: store is NULL");
+    std::lock_guard<std::mutex> lk(store->mu);
+    switch (option) {
+    case OEM_OPT_BATCH_BOOTSTRAP: store->batch_bootstrap = value != 0; return OEM_OK;
+    default: return fail(OEM_ERR_ARG, "oem_store_set_option: unknown option %u", option);
+    }
+}
+
 extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass)
 {
     if (!store) return fail(OEM_ERR_ARG, "oem_store_bytes: store is NULL");
@@ -453,7 +577,20 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
     OEM_TRY(ensure_row_w(s));
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
-    for (uint32_t b = 0; b < n_boot; ++b) {
+    uint32_t b_first = 0;
+    if (s->batch_bootstrap && can_batch(s) && max_iter >= 1) {
+        // kBatch replicates share each pass over the matrix; a trailing single replicate
+        // runs on the one-replicate path below
+        while (n_boot - b_first >= 2) {
+            const uint32_t nb = n_boot - b_first >= (uint32_t)kBatch ? (uint32_t)kBatch : n_boot - b_first;
+            bool fell_back = false;
+            OEM_TRY(run_bootstrap_batch(s, b_first, nb, seed, row_w_all, init_abundances, max_iter,
+                                        conv_thresh, out, infos, &fell_back));
+            if (fell_back) break;
+            b_first += nb;
+        }
+    }
+    for (uint32_t b = b_first; b < n_boot; ++b) {
         if (row_w_all) {
             OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (uint64_t)b * R, sizeof(uint32_t) * R,
                                    hipMemcpyHostToDevice, s->stream));

@@ -1,0 +1,476 @@
+// oem_batch_kernels.hip -- kBatch bootstrap replicates per pass over the resident matrix.
+//
+// em::bootstrap (em.rs:292-314) runs num_boot independent resampled EMs, each a serial
+// do_em over random_sampling_iter (em.rs:273-290).  Every replicate streams the whole
+// store again.  Here kBatch replicates share one pass over the tiled matrix: the
+// weights w and window codes are read once and folded against kBatch abundance
+// vectors (theta laid out [transcript][replicate], so one 32-byte access serves all
+// replicates of a transcript), each read scaled by its per-replicate multiplicity
+// c_ib ~ Multinomial(R; 1/R) (bootstrap.rs:7-16).
+//
+// Every replicate keeps its own loop state on the device and walks the reference's
+// state machine by itself: RUNNING -(stopping rule em.rs:212 / max_iter em.rs:181)->
+// FINAL (theta < 1e-5 zeroed, em.rs:238-242; one more pass, em.rs:245-252) ->
+// FINISHED (counts parked in `out`, replicate ignored from then on).
+#include <cstdlib>
+
+#include "oem_internal.h"
+
+namespace oem {
+
+namespace {
+
+constexpr int kB = kBatch;
+constexpr int kBThreads = 512;
+constexpr int kBWaves = kBThreads / 64;
+constexpr int kBPerWave = kTileSlices / kBWaves; // 2 slices per wavefront
+constexpr int kBCh = 8;                          // alignments per read kept in registers
+constexpr int kBRem = 3;                         // remote alignments per thread kept in registers
+constexpr int kFoldThreadsB = 1024;
+
+__device__ __forceinline__ void lds_add(double *p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct SliceRegsB {
+    float w[kBCh];
+    uint32_t c[kBCh / 2];
+};
+
+__device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restrict__ wbase,
+                                             const uint32_t *__restrict__ cbase, uint32_t lane,
+                                             uint32_t width)
+{
+#pragma unroll
+    for (int g = 0; g < kBCh / 2; ++g) {
+        if ((uint32_t)(2 * g) < width) {
+            r.w[2 * g] = wbase[(2 * g) * 64 + lane];
+            r.w[2 * g + 1] = wbase[(2 * g + 1) * 64 + lane];
+            r.c[g] = cbase[g * 64 + lane];
+        } else {
+            r.w[2 * g] = 0.f;
+            r.w[2 * g + 1] = 0.f;
+            r.c[g] = 0u;
+        }
+    }
+}
+
+// active[b] != 0 <=> replicate b still takes part in this pass (RUNNING or FINAL)
+__global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
+    const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
+    const float *__restrict__ w, const uint32_t *__restrict__ r_tid, const float *__restrict__ r_w,
+    const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
+    double *__restrict__ queue /* [kB][n_remote] */, uint64_t n_remote,
+    const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
+    const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
+{
+    uint32_t act = 0;
+#pragma unroll
+    for (int b = 0; b < kB; ++b) act |= (st[b].phase != kPhaseFinished) ? (1u << b) : 0u;
+    if (!act) return;
+
+    __shared__ double theta_l[kWin * kB];
+    __shared__ double cnt_l[kWin * kB];
+    __shared__ double den_l[kTileRows * kB];
+
+    const TileDesc td = tiles[blockIdx.x];
+    const uint32_t tx = threadIdx.x;
+    const uint32_t lane = tx & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);
+
+    uint32_t woff[kBPerWave], coff[kBPerWave], wid[kBPerWave];
+    {
+        uint32_t accw = td.w_base, accc = td.c_base;
+#pragma unroll
+        for (uint32_t i = 0; i < kTileSlices; ++i) {
+            const uint32_t wi = td.width[i];
+            if ((i % kBWaves) == wave) {
+                woff[i / kBWaves] = accw;
+                coff[i / kBWaves] = accc;
+                wid[i / kBWaves] = wi;
+            }
+            accw += wi;
+            accc += (wi + 1) >> 1;
+        }
+    }
+    SliceRegsB R[kBPerWave];
+#pragma unroll
+    for (uint32_t q = 0; q < kBPerWave; ++q)
+        load_slice_b(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+
+    // remote alignments of this thread: x[b] = theta[t][b] * w
+    double rx[kBRem][kB];
+    uint32_t rrow[kBRem], rslot[kBRem];
+#pragma unroll
+    for (int k = 0; k < kBRem; ++k) {
+        const uint32_t i = tx + k * kBThreads;
+        rrow[k] = 0;
+        rslot[k] = 0;
+#pragma unroll
+        for (int b = 0; b < kB; ++b) rx[k][b] = 0.0;
+        if (i < td.remote_cnt) {
+            const uint32_t o = td.remote_begin + i;
+            const uint32_t t = r_tid[o];
+            const double wv = (double)r_w[o];
+            rrow[k] = r_row[o];
+            rslot[k] = r_slot[o];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) rx[k][b] = theta[(size_t)t * kB + b] * wv;
+        }
+    }
+    for (uint32_t i = tx; i < td.win_len * kB; i += kBThreads) {
+        theta_l[i] = theta[(size_t)td.lo * kB + i];
+        cnt_l[i] = 0.0;
+    }
+    for (uint32_t i = tx; i < td.n_slices * 64 * kB; i += kBThreads) den_l[i] = 0.0;
+    __syncthreads();
+
+    // remote phase A: denominators
+#pragma unroll
+    for (int k = 0; k < kBRem; ++k)
+        if (tx + k * kBThreads < td.remote_cnt) {
+#pragma unroll
+            for (int b = 0; b < kB; ++b) lds_add(&den_l[rrow[k] * kB + b], rx[k][b]);
+        }
+    for (uint32_t i = tx + kBRem * kBThreads; i < td.remote_cnt; i += kBThreads) { // overflow: park in the queue
+        const uint32_t o = td.remote_begin + i;
+        const uint32_t t = r_tid[o];
+        const double wv = (double)r_w[o];
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            const double x = theta[(size_t)t * kB + b] * wv;
+            queue[(size_t)b * n_remote + r_slot[o]] = x;
+            lds_add(&den_l[r_row[o] * kB + b], x);
+        }
+    }
+    __syncthreads();
+
+    // local alignments
+#pragma unroll
+    for (uint32_t q = 0; q < kBPerWave; ++q) {
+        const uint32_t s = wave + kBWaves * q;
+        if (s >= td.n_slices) continue;
+        const uint32_t width = wid[q];
+        const uint32_t rl = s * 64 + lane;
+        const float *wbase = w + (size_t)woff[q] * 64;
+        const uint32_t *cbase = codes + (size_t)coff[q] * 64;
+        uint32_t mult = 0; // packed multiplicities of this read, one byte per replicate
+        if (rl < td.n_rows) mult = *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB);
+        double inv[kB];
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            double denom = den_l[rl * kB + b];
+#pragma unroll
+            for (int k = 0; k < kBCh; ++k) {
+                const uint32_t off = (k & 1) ? (R[q].c[k >> 1] >> 16) : (R[q].c[k >> 1] & 0xffffu);
+                const double wk = (uint32_t)k < width ? (double)R[q].w[k] : 0.0;
+                denom += theta_l[(off >> 3) * kB + b] * wk;                     // em.rs:111
+            }
+            for (uint32_t j = kBCh; j < width; ++j) {
+                const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+                const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+                denom += theta_l[(off >> 3) * kB + b] * (double)wbase[j * 64 + lane];
+            }
+            const double scale = (double)((mult >> (8 * b)) & 0xffu);
+            inv[b] = ((act >> b) & 1u) && denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0; // em.rs:115
+            den_l[rl * kB + b] = inv[b];
+        }
+#pragma unroll
+        for (int k = 0; k < kBCh; ++k) {
+            if ((uint32_t)k < width) {
+                const uint32_t off = (k & 1) ? (R[q].c[k >> 1] >> 16) : (R[q].c[k >> 1] & 0xffffu);
+                const double wk = (double)R[q].w[k];
+#pragma unroll
+                for (int b = 0; b < kB; ++b) {
+                    const double v = theta_l[(off >> 3) * kB + b] * wk * inv[b];
+                    if (v != 0.0) lds_add(&cnt_l[(off >> 3) * kB + b], v);      // em.rs:128-129
+                }
+            }
+        }
+        for (uint32_t j = kBCh; j < width; ++j) {
+            const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+            const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+            const double wk = (double)wbase[j * 64 + lane];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) {
+                const double v = theta_l[(off >> 3) * kB + b] * wk * inv[b];
+                if (v != 0.0) lds_add(&cnt_l[(off >> 3) * kB + b], v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // remote phase B: queue[b][slot] <- x_b * (c_ib / denom_ib)
+#pragma unroll
+    for (int k = 0; k < kBRem; ++k) {
+        const uint32_t i = tx + k * kBThreads;
+        if (i < td.remote_cnt) {
+#pragma unroll
+            for (int b = 0; b < kB; ++b)
+                queue[(size_t)b * n_remote + rslot[k]] = rx[k][b] * den_l[rrow[k] * kB + b];
+        }
+    }
+    for (uint32_t i = tx + kBRem * kBThreads; i < td.remote_cnt; i += kBThreads) {
+        const uint32_t o = td.remote_begin + i;
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            const size_t qi = (size_t)b * n_remote + r_slot[o];
+            queue[qi] = queue[qi] * den_l[r_row[o] * kB + b];
+        }
+    }
+    // flush: the window is contiguous in [T][kB]
+    for (uint32_t i = tx; i < td.win_len * kB; i += kBThreads) {
+        const double v = cnt_l[i];
+        if (v != 0.0) unsafeAtomicAdd(&cnt[(size_t)td.lo * kB + i], v);
+    }
+}
+
+// one workgroup per (replicate, bucket, group): streams queue[b][range] into an LDS window and
+// flushes it into cnt2[b][.] (replicate-major, so the flush is line-coalesced)
+__global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
+    const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue, uint64_t n_remote,
+    const uint16_t *__restrict__ q_dst, double *__restrict__ cnt2 /* [kB][T] */,
+    const BatchState *__restrict__ st, uint32_t n_groups, uint32_t n_buckets, uint32_t n_txps)
+{
+    const uint32_t b = blockIdx.x / (n_groups * n_buckets);
+    if (st[b].phase == kPhaseFinished) return;
+    const uint32_t rest = blockIdx.x % (n_groups * n_buckets);
+    const uint32_t bk = rest / n_groups, g = rest % n_groups;
+    __shared__ double acc[kBucket];
+    const uint32_t q0 = bucket_base[bk], q1 = bucket_base[bk + 1];
+    const uint64_t span = q1 - q0;
+    const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups);
+    const uint32_t s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
+    if (s0 == s1) return;
+    for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreadsB) acc[i] = 0.0;
+    __syncthreads();
+    const double *qb = queue + (size_t)b * n_remote;
+    uint32_t o = s0 + threadIdx.x;
+    for (; o + 3 * kFoldThreadsB < s1; o += 4 * kFoldThreadsB) {
+        double v[4];
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = qb[o + k * kFoldThreadsB];
+            d[k] = q_dst[o + k * kFoldThreadsB];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (v[k] != 0.0) lds_add(&acc[d[k]], v[k]);
+    }
+    for (; o < s1; o += kFoldThreadsB) {
+        const double v = qb[o];
+        if (v != 0.0) lds_add(&acc[q_dst[o]], v);
+    }
+    __syncthreads();
+    const uint32_t base = bk * kBucket;
+    for (uint32_t i = threadIdx.x; i < kBucket && base + i < n_txps; i += kFoldThreadsB) {
+        const double v = acc[i];
+        if (v != 0.0) unsafeAtomicAdd(&cnt2[(size_t)b * n_txps + base + i], v);
+    }
+}
+
+// rel-diff / swap / clear / state machine for kB replicates (em.rs:194-218, :238-254)
+//   curr_b[t] = cnt[t][b] + cnt2[b][t]
+__global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
+                                                   double *__restrict__ cnt2, double *__restrict__ out,
+                                                   BatchState *st, EmParams p)
+{
+    uint32_t phase[kB];
+    uint32_t any = 0;
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+        phase[b] = st[b].phase;
+        any |= phase[b] != kPhaseFinished;
+    }
+    if (!any) return;
+    double rel[kB];
+#pragma unroll
+    for (int b = 0; b < kB; ++b) rel[b] = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            if (phase[b] == kPhaseFinished) continue;
+            const size_t ia = (size_t)i * kB + b, ib = (size_t)b * p.n_txps + i;
+            const double cc = cnt[ia] + cnt2[ib];
+            cnt[ia] = 0.0;
+            cnt2[ib] = 0.0;
+            if (phase[b] == kPhaseFinal) {
+                out[ib] = cc;                               // em.rs:254
+            } else {
+                const double pc = theta[ia];
+                if (pc > OEM_MIN_READ_THRESH) rel[b] = fmax(rel[b], (cc - pc) / pc); // em.rs:195-199
+                theta[ia] = cc;                             // em.rs:204 (zeroing of small values: below)
+            }
+        }
+    }
+    __shared__ double smax[256 / 64][kB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+        double r = rel[b];
+        for (int off = 32; off > 0; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
+        if (lane == 0) smax[wv][b] = r;
+    }
+    __syncthreads();
+    __shared__ bool is_last;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            double m = smax[0][b];
+            for (int i = 1; i < 256 / 64; ++i) m = fmax(m, smax[i][b]);
+            if (m > 0.0) atomicMax(&st[b].rel_bits, (unsigned long long)__double_as_longlong(m));
+        }
+        __threadfence();
+        const uint32_t ticket = atomicAdd(&st[0].blocks_arrived, 1u);
+        is_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x == 0) {
+        __threadfence();
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            if (phase[b] == kPhaseFinished) continue;
+            if (phase[b] == kPhaseFinal) {
+                st[b].n_passes += 1;
+                st[b].phase = kPhaseFinished;
+                continue;
+            }
+            const unsigned long long bits =
+                __hip_atomic_load(&st[b].rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double rel_diff = __longlong_as_double((long long)bits);
+            st[b].last_rel = rel_diff;
+            st[b].n_passes += 1;
+            uint32_t niter = st[b].niter;
+            if (rel_diff < p.conv_thresh && niter > p.min_iter_gate) { // em.rs:212
+                st[b].converged = 1;
+                st[b].phase = kPhaseFinal;
+            } else {
+                niter += 1;                                            // em.rs:218
+                st[b].niter = niter;
+                if (niter >= p.max_iter) st[b].phase = kPhaseFinal;    // em.rs:181
+            }
+            st[b].rel_bits = 0ull;
+        }
+        st[0].blocks_arrived = 0u;
+    }
+}
+
+// em.rs:238-242 for the replicates that just entered FINAL (needs_zero set by the host-side
+// bookkeeping kernel below is avoided: the flag lives in the state and is cleared here)
+__global__ __launch_bounds__(256) void k_zero_small_b(double *__restrict__ theta, BatchState *st, uint32_t n_txps)
+{
+    uint32_t z = 0;
+#pragma unroll
+    for (int b = 0; b < kB; ++b)
+        if (st[b].phase == kPhaseFinal && !st[b].zeroed) z |= 1u << b;
+    if (!z) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int b = 0; b < kB; ++b)
+            if (((z >> b) & 1u) && theta[(size_t)i * kB + b] < OEM_MIN_READ_THRESH) theta[(size_t)i * kB + b] = 0.0;
+    }
+}
+__global__ void k_mark_zeroed_b(BatchState *st)
+{
+    const int b = threadIdx.x;
+    if (b < kB && st[b].phase == kPhaseFinal) st[b].zeroed = 1;
+}
+
+// theta[t][b] = value (uniform init) or init[t]
+__global__ __launch_bounds__(256) void k_init_theta_b(double *__restrict__ theta, const double *__restrict__ init,
+                                                      double avg, uint32_t n_txps)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
+        const double v = init ? init[i] : avg;
+#pragma unroll
+        for (int b = 0; b < kB; ++b) theta[(size_t)i * kB + b] = v;
+    }
+}
+
+// multiplicities of kB replicates, caller order u32 [kB][R] -> tile order u8 [rows][kB];
+// *overflow is set if a multiplicity does not fit a byte (the caller then falls back to the
+// one-replicate-per-pass path)
+__global__ __launch_bounds__(256) void k_pack_row_w_b(const uint32_t *__restrict__ row_w, uint64_t n_reads,
+                                                      const uint32_t *__restrict__ perm, uint64_t n_rows,
+                                                      uint8_t *__restrict__ out, uint32_t *overflow)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = perm[i];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < kB; ++b) {
+            const uint32_t c = row_w[(uint64_t)b * n_reads + r];
+            if (c > 255u) *overflow = 1u;
+            packed |= (c & 0xffu) << (8 * b);
+        }
+        *reinterpret_cast<uint32_t *>(out + i * kB) = packed;
+    }
+}
+
+inline int grid_for(uint64_t n, int block, int max_blocks)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+} // namespace
+
+int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
+{
+    const DeviceTiled &t = s->tiled;
+    if (t.n_tiles == 0) return OEM_OK;
+    hipLaunchKernelGGL(k_em_tile_b, dim3(t.n_tiles), dim3(kBThreads), 0, s->stream, t.tiles, t.codes,
+                       (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
+                       t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
+    OEM_HIP(hipGetLastError());
+    if (t.n_remote > 0) {
+        uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);
+        const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
+        const uint32_t max_useful = (uint32_t)((per_bucket + 4095) / 4096);
+        if (n_groups > max_useful) n_groups = max_useful;
+        if (n_groups < 1) n_groups = 1;
+        hipLaunchKernelGGL(k_remote_fold_b, dim3(kB * t.n_buckets * n_groups), dim3(kFoldThreadsB), 0, s->stream,
+                           t.bucket_base, bb.queue, t.n_remote, t.q_dst, bb.cnt2, bb.state, n_groups,
+                           t.n_buckets, s->csr.n_txps);
+        OEM_HIP(hipGetLastError());
+    }
+    return OEM_OK;
+}
+
+int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
+{
+    const int grid = grid_for(p.n_txps, 256, 256);
+    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
+                       bb.state, p);
+    // replicates that just entered FINAL get their small abundances zeroed before the next pass
+    hipLaunchKernelGGL(k_zero_small_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.state, p.n_txps);
+    hipLaunchKernelGGL(k_mark_zeroed_b, dim3(1), dim3(64), 0, s->stream, bb.state);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg)
+{
+    const int grid = grid_for(s->csr.n_txps, 256, 256);
+    hipLaunchKernelGGL(k_init_theta_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, d_init, avg,
+                       s->csr.n_txps);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow)
+{
+    const uint64_t n = s->tiled.n_rows;
+    if (n == 0) return OEM_OK;
+    hipLaunchKernelGGL(k_pack_row_w_b, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s->stream, d_row_w_all,
+                       s->csr.n_reads, s->tiled.perm, n, bb.row_w, d_overflow);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+} // namespace oem

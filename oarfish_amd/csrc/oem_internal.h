@@ -104,6 +104,41 @@ struct DeviceTiled {
     uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
 };
 
+// ---------------------------------------------------------------------------
+// Batched bootstrap: kBatch replicates share each pass over the matrix
+// (oem_batch_kernels.hip).  Per-replicate loop state, walked on the device:
+// RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
+// ---------------------------------------------------------------------------
+constexpr int kBatch = 4;
+enum : uint32_t { kPhaseRunning = 0, kPhaseFinal = 1, kPhaseFinished = 2 };
+
+struct BatchState {
+    unsigned long long rel_bits;
+    double last_rel;
+    uint32_t niter;
+    uint32_t n_passes;
+    uint32_t converged;
+    uint32_t blocks_arrived; // only [0] is used
+    uint32_t phase;
+    uint32_t zeroed;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BatchState) == 48, "BatchState layout");
+
+struct BatchBuffers {
+    double *theta = nullptr;   // [T][kBatch]
+    double *cnt = nullptr;     // [T][kBatch]  (tile-kernel flushes)   } contiguous: one all-reduce
+    double *cnt2 = nullptr;    // [kBatch][T]  (fold-kernel flushes)   }
+    double *out = nullptr;     // [kBatch][T]
+    double *queue = nullptr;   // [kBatch][n_remote]
+    BatchState *state = nullptr;
+    uint8_t *row_w = nullptr;  // [rows][kBatch], tile order
+    uint32_t *row_w_all = nullptr; // [kBatch][R] u32, caller order (drawn or injected)
+    uint32_t *overflow = nullptr;
+    BatchState *h_state = nullptr; // pinned
+    double *h_out = nullptr;       // pinned [kBatch][T]
+};
+
 struct Comm; // oem_comm.cpp
 
 } // namespace oem
@@ -120,6 +155,8 @@ struct oem_store {
     oem::EmState *h_state = nullptr;     // pinned
     uint32_t *d_row_w = nullptr;         // bootstrap multiplicities, n_reads u32
     double *h_pinned = nullptr;          // pinned staging, n_txps f64
+    oem::BatchBuffers batch;             // lazily allocated by the batched bootstrap
+    bool batch_bootstrap = false;        // OEM_OPT_BATCH_BOOTSTRAP
     // multi-GPU
     oem::Comm *comm = nullptr;
     uint64_t global_n_reads = 0;
@@ -151,6 +188,12 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm);
 int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_perm);
+
+// batched bootstrap (oem_batch_kernels.hip)
+int launch_batch_pass(oem_store *s, const BatchBuffers &bb);
+int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p);
+int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg);
+int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow);
 
 int launch_fill(oem_store *s, double *p, double v, uint64_t n);
 int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,

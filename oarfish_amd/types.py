@@ -104,6 +104,9 @@ class DeviceStore:
         _lib.check(_lib.lib().oem_store_bytes(self.handle, C.byref(hbm), C.byref(alg)))
         return int(hbm.value), int(alg.value)
 
+    def set_option(self, option: int, value: int):
+        _lib.check(_lib.lib().oem_store_set_option(self.handle, option, value))
+
     # -- compute ----------------------------------------------------------
     def m_step(self, theta, row_w=None) -> np.ndarray:
         theta = np.ascontiguousarray(theta, dtype=np.float64)

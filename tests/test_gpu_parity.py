@@ -121,6 +121,49 @@ def test_bootstrap_inject_golden():
         assert_counts_close(out[b], g["boot_counts"][b], 600, 40, 1e-6, f"replicate {b}")
 
 
+def test_batched_bootstrap_matches_oracle_per_replicate():
+    """Replicates share passes over the matrix in batches of 4 (a trailing one runs alone); every
+    replicate must still stop at its own iteration and match its own serial EM."""
+    st = synth.make_store(40_000, 2_500, seed=81)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    rng = np.random.default_rng(8)
+    n_boot = 7  # 4 + 3
+    W = np.stack([np.bincount(rng.integers(0, st.n_reads, st.n_reads), minlength=st.n_reads)
+                  for _ in range(n_boot)]).astype(np.uint32)
+    W[5] = 1      # the un-resampled store: must equal the point estimate
+    from oarfish_amd import _lib
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        d.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 1)
+        out, infos = d.bootstrap(n_boot, row_w_all=W, max_iter=300, conv_thresh=1e-3)
+        point, pinfo = d.em_run(None, 300, 1e-3, 50)
+        # a multiplicity that does not fit a byte forces the one-replicate-per-pass path
+        W2 = W[:4].copy()
+        W2[2, :] = 0
+        W2[2, :5] = 300
+        out2, infos2 = d.bootstrap(4, row_w_all=W2, max_iter=120, conv_thresh=1e-3)
+        # single iteration budget: every replicate leaves through max_iter
+        out3, infos3 = d.bootstrap(4, row_w_all=W[:4], max_iter=1, conv_thresh=1e-3)
+    niters = set()
+    for b in range(n_boot):
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=300, conv_thresh=1e-3)
+        assert abs(infos[b].niter - wi.niter) <= 1, (b, infos[b], wi)
+        assert infos[b].converged == wi.converged
+        if infos[b].niter == wi.niter:
+            assert infos[b].n_passes == wi.n_passes
+        assert_counts_close(out[b], want, st.n_reads, st.n_txps, RTOL if infos[b].niter != wi.niter else 1e-8,
+                            f"replicate {b}")
+        niters.add(wi.niter)
+    assert len(niters) > 1, "replicates should stop at different iterations in this test"
+    assert abs(infos[5].niter - pinfo.niter) <= 1
+    assert_counts_close(out[5], point, st.n_reads, st.n_txps, RTOL, "identity resample")
+    for b in range(4):
+        want, wi = c_oracle.do_em(o, row_w=W2[b], max_iter=120, conv_thresh=1e-3)
+        assert_counts_close(out2[b], want, st.n_reads, st.n_txps, RTOL, f"fallback replicate {b}")
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=1, conv_thresh=1e-3)
+        assert infos3[b].niter == 1 and infos3[b].n_passes == 2
+        assert_counts_close(out3[b], want, st.n_reads, st.n_txps, 1e-9, f"max_iter=1 replicate {b}")
+
+
 def test_device_multinomial_weights():
     """bootstrap.rs:7-16: Multinomial(n; 1/n): sum n, mean 1, var 1-1/n, P(0)=e^-1,
     replicas independent, stream reproducible."""
