@@ -315,6 +315,7 @@ void free_store(oem_store *s)
         if (b.h_state) hipHostFree(b.h_state);
         if (b.h_out) hipHostFree(b.h_out);
     }
+    hipFree(s->multi.state); hipFree(s->multi.out); hipFree(s->multi.n_unfinished);
     hipFree(s->theta);
     hipFree(s->cnt);
     hipFree(s->d_state);
@@ -362,6 +363,8 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     t.present = true;
     return OEM_OK;
 }
+
+thread_local uint32_t t_problem_size = 0; // set by oem_em_run_cells around its store creation
 
 int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                       const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
@@ -415,7 +418,7 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     if (reorder != 1 && n_reads > 0) {
         TiledHost h;
         const char *err = nullptr;
-        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err)) {
+        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err, t_problem_size)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
             return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
@@ -616,18 +619,142 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
 // ---------------------------------------------------------------------------
 // single-cell batch (v1: cells run back to back on the resident matrix)
 // ---------------------------------------------------------------------------
+namespace oem {
+namespace {
+
+// All cells in one store over the concatenated transcript space; every pass serves every
+// unfinished cell.  Returns *used = false (nothing done) when the batch form does not apply.
+int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint64_t *row_ptr,
+                      const uint32_t *tid, const float *as_prob, const double *cov_prob, uint64_t n_reads,
+                      uint64_t nnz, uint32_t n_txps, int device, uint32_t max_iter, double conv_thresh,
+                      double *out, oem_run_info *infos, bool *used)
+{
+    *used = false;
+    const uint64_t total_txps = (uint64_t)n_cells * n_txps;
+    if (max_iter < 1 || n_cells < 2 || total_txps >= (1ull << 32) || n_reads >= (1ull << 32)) return OEM_OK;
+    // transcripts of cell p -> [p*T, (p+1)*T)
+    std::vector<uint32_t> vt(nnz);
+    for (uint32_t c = 0; c < n_cells; ++c) {
+        const uint64_t a0 = row_ptr[cell_row_off[c]], a1 = row_ptr[cell_row_off[c + 1]];
+        const uint32_t base = c * n_txps;
+        for (uint64_t j = a0; j < a1; ++j) {
+            if (tid[j] >= n_txps) return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u",
+                                              (unsigned long long)j, tid[j], n_txps);
+            vt[j] = base + tid[j];
+        }
+    }
+    oem_store *s = nullptr;
+    t_problem_size = n_txps;
+    oem_store_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    opts.reorder_rows = 2;
+    int rc = oem_store_create(row_ptr, vt.data(), as_prob, cov_prob, n_reads, nnz, (uint32_t)total_txps, device,
+                              &opts, &s);
+    t_problem_size = 0;
+    if (rc != OEM_OK) return rc;
+    std::vector<uint32_t>().swap(vt);
+    *used = true;
+
+    auto body = [&]() -> int {
+        MultiBuffers &mb = s->multi;
+        mb.n_problems = n_cells;
+        mb.problem_size = n_txps;
+        OEM_TRY(dev_alloc(&mb.state, n_cells, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&mb.out, (size_t)total_txps, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&mb.n_unfinished, 1, &s->hbm_bytes));
+        std::vector<BatchState> hs(n_cells);
+        std::vector<uint64_t> reads(n_cells);
+        for (uint32_t c = 0; c < n_cells; ++c) {
+            std::memset(&hs[c], 0, sizeof(BatchState));
+            hs[c].phase = kPhaseRunning;
+            reads[c] = cell_row_off[c + 1] - cell_row_off[c]; // the cell's own store.len() (single_cell.rs:122-130)
+        }
+        uint64_t *d_reads = nullptr;
+        OEM_TRY(dev_alloc(&d_reads, n_cells, nullptr));
+        int rc2 = OEM_OK;
+        do {
+            if (hipMemcpyAsync(d_reads, reads.data(), sizeof(uint64_t) * n_cells, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(mb.state, hs.data(), sizeof(BatchState) * n_cells, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemcpyAsync(mb.n_unfinished, &n_cells, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+                hipMemsetAsync(s->cnt, 0, sizeof(double) * total_txps, s->stream) != hipSuccess) {
+                rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: upload of the per-cell state failed");
+                break;
+            }
+            if ((rc2 = launch_multi_init(s, s->theta, d_reads, mb)) != OEM_OK) break;
+            EmParams p{n_txps, max_iter, 50u /* em::em, single_cell.rs:150 */, conv_thresh};
+            const uint32_t total = max_iter + 1;
+            uint32_t launched = 0, unfinished = n_cells;
+            while (launched < total && unfinished) {
+                uint32_t chunk = launched == 0 ? 53 : 16;
+                if (chunk > total - launched) chunk = total - launched;
+                for (uint32_t k = 0; k < chunk && rc2 == OEM_OK; ++k) {
+                    rc2 = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, mb.state, n_txps);
+                    if (rc2 == OEM_OK) rc2 = launch_multi_reldiff(s, s->theta, s->cnt, mb, p);
+                }
+                if (rc2 != OEM_OK) break;
+                launched += chunk;
+                if (hipMemcpyAsync(&unfinished, mb.n_unfinished, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                    hipStreamSynchronize(s->stream) != hipSuccess) {
+                    rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: state read-back failed");
+                    break;
+                }
+            }
+            if (rc2 != OEM_OK) break;
+            if (hipMemcpy(out, mb.out, sizeof(double) * total_txps, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(hs.data(), mb.state, sizeof(BatchState) * n_cells, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: result read-back failed");
+                break;
+            }
+            if (infos)
+                for (uint32_t c = 0; c < n_cells; ++c) {
+                    infos[c].niter = hs[c].niter;
+                    infos[c].n_passes = hs[c].n_passes;
+                    infos[c].converged = hs[c].converged;
+                    infos[c].reserved = 0;
+                    infos[c].rel_diff = hs[c].last_rel;
+                }
+        } while (false);
+        hipFree(d_reads);
+        return rc2;
+    };
+    rc = body();
+    free_store(s);
+    return rc;
+}
+
+} // namespace
+} // namespace oem
+
+// ---------------------------------------------------------------------------
+// single-cell batch
+// ---------------------------------------------------------------------------
 extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, const uint64_t *row_ptr,
                                 const uint32_t *tid, const float *as_prob, const double *cov_prob,
                                 uint64_t n_reads, uint64_t nnz, uint32_t n_txps, int device,
                                 uint32_t max_iter, double conv_thresh, double *out,
                                 oem_run_info *infos)
 {
-    if (!cell_row_off || (n_cells && !out)) return fail(OEM_ERR_ARG, "oem_em_run_cells: NULL argument");
+    if (!cell_row_off || !row_ptr || (n_cells && !out)) return fail(OEM_ERR_ARG, "oem_em_run_cells: NULL argument");
+    if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_em_run_cells: n_txps is 0");
     if (cell_row_off[0] != 0 || cell_row_off[n_cells] != n_reads)
         return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off must span [0, n_reads]");
     for (uint32_t c = 0; c < n_cells; ++c)
         if (cell_row_off[c + 1] < cell_row_off[c])
             return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off not non-decreasing at cell %u", c);
+    if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_em_run_cells: tid/as_prob is NULL");
+    for (uint64_t i = 0; i < n_reads; ++i)
+        if (row_ptr[i + 1] < row_ptr[i]) return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu", (unsigned long long)i);
+    if (row_ptr[0] != 0 || row_ptr[n_reads] != nnz) return fail(OEM_ERR_ARG, "oem_em_run_cells: row_ptr must span [0, nnz]");
+
+    // batched on the device: every pass over the resident store serves all unfinished cells
+    static const bool serial_cells = getenv("OEM_SERIAL_CELLS") != nullptr; // A/B knob
+    if (!serial_cells) {
+        bool used = false;
+        int rcb = run_cells_batched(cell_row_off, n_cells, row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps,
+                                    device, max_iter, conv_thresh, out, infos, &used);
+        if (rcb != OEM_OK || used) return rcb;
+    }
+    // fallback (max_iter == 0, one cell, or a transcript space beyond 2^32): cells one after another
     oem_store *s = nullptr;
     oem_store_opts opts;
     std::memset(&opts, 0, sizeof(opts));

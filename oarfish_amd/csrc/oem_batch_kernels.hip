@@ -322,13 +322,12 @@ __global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, d
             for (int i = 1; i < 256 / 64; ++i) m = fmax(m, smax[i][b]);
             if (m > 0.0) atomicMax(&st[b].rel_bits, (unsigned long long)__double_as_longlong(m));
         }
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t ticket = atomicAdd(&st[0].blocks_arrived, 1u);
         is_last = (ticket == gridDim.x - 1);
     }
     __syncthreads();
     if (is_last && threadIdx.x == 0) {
-        __threadfence();
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
             if (phase[b] == kPhaseFinished) continue;
@@ -431,7 +430,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     if (t.n_remote > 0) {
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);
         const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
-        const uint32_t max_useful = (uint32_t)((per_bucket + 4095) / 4096);
+        const uint32_t max_useful = (uint32_t)((per_bucket + 32767) / 32768);
         if (n_groups > max_useful) n_groups = max_useful;
         if (n_groups < 1) n_groups = 1;
         hipLaunchKernelGGL(k_remote_fold_b, dim3(kB * t.n_buckets * n_groups), dim3(kFoldThreadsB), 0, s->stream,

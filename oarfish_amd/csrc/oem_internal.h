@@ -139,6 +139,18 @@ struct BatchBuffers {
     double *h_out = nullptr;       // pinned [kBatch][T]
 };
 
+// Per-cell batch: the cells are laid out as one store over a concatenated transcript
+// space (problem p owns transcripts [p*T, (p+1)*T)); every problem carries its own loop
+// state and walks RUNNING -> FINAL -> FINISHED on the device (oem_multi_kernels.hip).
+struct MultiBuffers {
+    uint32_t n_problems = 0;
+    uint32_t problem_size = 0;
+    BatchState *state = nullptr;   // [n_problems]
+    BatchState *h_state = nullptr; // host copy
+    double *out = nullptr;         // [n_problems * problem_size]
+    uint32_t *n_unfinished = nullptr; // device counter
+};
+
 struct Comm; // oem_comm.cpp
 
 } // namespace oem
@@ -156,6 +168,7 @@ struct oem_store {
     uint32_t *d_row_w = nullptr;         // bootstrap multiplicities, n_reads u32
     double *h_pinned = nullptr;          // pinned staging, n_txps f64
     oem::BatchBuffers batch;             // lazily allocated by the batched bootstrap
+    oem::MultiBuffers multi;             // per-cell batches
     bool batch_bootstrap = false;        // OEM_OPT_BATCH_BOOTSTRAP
     // multi-GPU
     oem::Comm *comm = nullptr;
@@ -186,7 +199,11 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 // Tiled E/M pass over the whole store (oem_layout.h): tile kernel + remote-bucket kernel.
 // row_w is in the caller's read order; it is permuted into tile order first.
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
-                         const uint32_t *row_w_perm);
+                         const uint32_t *row_w_perm, const BatchState *problems = nullptr,
+                         uint32_t problem_size = 0);
+// per-cell batches (oem_multi_kernels.hip)
+int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
+int launch_multi_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_perm);
 
 // batched bootstrap (oem_batch_kernels.hip)

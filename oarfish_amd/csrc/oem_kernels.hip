@@ -89,15 +89,16 @@ __global__ __launch_bounds__(kBlock) void k_reldiff_swap_clear(double *__restric
     if (threadIdx.x == 0) {
         double m = smax[0];
         for (int i = 1; i < kBlock / 64; ++i) m = fmax(m, smax[i]);
-        // non-negative doubles order like their bit patterns
+        // non-negative doubles order like their bit patterns.  Both this and the ticket below are
+        // device-scope atomics resolved at the memory side; draining the max (vmcnt) before taking
+        // the ticket orders them without a cache write-back/invalidate (~3.5 us each on MI355X).
         if (m > 0.0) atomicMax(&state->rel_bits, (unsigned long long)__double_as_longlong(m));
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t ticket = atomicAdd(&state->blocks_arrived, 1u);
         is_last = (ticket == gridDim.x - 1);
     }
     __syncthreads();
     if (is_last && threadIdx.x == 0) {
-        __threadfence();
         const unsigned long long bits =
             __hip_atomic_load(&state->rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double rel_diff = __longlong_as_double((long long)bits);

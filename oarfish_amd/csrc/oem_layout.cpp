@@ -55,7 +55,7 @@ struct RemoteRec {
 
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err)
+                        TiledHost *out, const char **err, uint32_t problem_size)
 {
     (void)nnz;
     if (n_reads >= (1ull << 32)) {
@@ -122,7 +122,11 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             const uint32_t k0 = key[order[pos]];
             uint32_t lo = k0 > kMargin ? k0 - kMargin : 0;
             lo &= ~7u;
-            const uint32_t kmax = lo + kWin - kMargin - 1;
+            uint32_t kmax = lo + kWin - kMargin - 1;
+            if (problem_size) { // stay inside the problem of the first read
+                const uint32_t pend = (k0 / problem_size + 1) * problem_size - 1;
+                if (kmax > pend) kmax = pend;
+            }
             uint32_t end = pos + 1;
             while (end < n_rows && end - pos < kTileRows && key[order[end]] <= kmax) ++end;
             tile_start.push_back(pos);
@@ -205,6 +209,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
         td.row_base = tile_start[ti];
         td.lo = tile_lo[ti];
         td.win_len = tile_win[ti];
+        td.problem = problem_size ? key[order[tile_start[ti]]] / problem_size : 0;
         td.remote_begin = (uint32_t)n_remote;
         td.remote_cnt = sizes[ti].remote_cnt;
         w_base[ti] = w_slots;

@@ -52,7 +52,8 @@ struct TileDesc { // 64 bytes
     uint32_t c_base;       // codes   of slice s start at (c_base + sum_{i<s} (width[i]+1)/2) * 64
     uint8_t width[kTileSlices]; // max local alignments of the 64 reads of each slice (0 = no slice)
     uint32_t n_slices;
-    uint32_t pad[3];
+    uint32_t problem;      // independent EM problem the tile belongs to (per-cell batches); 0 otherwise
+    uint32_t pad[2];
 };
 static_assert(sizeof(TileDesc) == 64, "TileDesc layout");
 static_assert(kTileSlices == 16, "TileDesc::width is sized for 16 slices");
@@ -84,8 +85,11 @@ struct TiledHost {
 // Builds the layout from the caller's CSR.  w = (f64)as_prob * cov_prob when
 // cov_prob != nullptr (em.rs:107-111), else as_prob (exact f32).
 // Returns false (with `err`) if the store cannot be tiled (n_reads >= 2^32).
+// `problem_size` > 0 declares the transcript space to be the concatenation of independent
+// problems of that many transcripts each (per-cell EM, single_cell.rs:139-160): tiles then
+// never mix reads of two problems.
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err);
+                        TiledHost *out, const char **err, uint32_t problem_size = 0);
 
 } // namespace oem

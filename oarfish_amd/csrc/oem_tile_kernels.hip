@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
-    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate)
+    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate,
+    const BatchState *__restrict__ problems)
 {
     if (state && state->done) return;
 
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
+    if (problems && problems[td.problem].phase == kPhaseFinished) return; // per-cell batch: this cell is done
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6); // SGPR: slice control flow is scalar
@@ -274,11 +276,20 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
     const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, const EmState *state,
-    uint32_t n_groups, uint32_t n_txps)
+    uint32_t n_groups, uint32_t n_txps, const BatchState *__restrict__ problems, uint32_t problem_size)
 {
     if (state && state->done) return;
     __shared__ double acc[kBucket];
     const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
+    if (problems) { // per-cell batch: skip the bucket when every cell it touches is finished
+        const uint32_t t0 = b * kBucket;
+        uint32_t t1 = t0 + kBucket - 1;
+        if (t1 >= n_txps) t1 = n_txps - 1;
+        bool live = false;
+        for (uint32_t p = t0 / problem_size; p <= t1 / problem_size; ++p)
+            live = live || problems[p].phase != kPhaseFinished;
+        if (!live) return;
+    }
     const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
     const uint64_t span = q1 - q0;
     const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups);
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 template <typename WT>
 static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT *r_w,
                                 const double *theta, double *cnt, const EmState *state,
-                                const uint32_t *row_w_perm)
+                                const uint32_t *row_w_perm, const BatchState *problems)
 {
     const DeviceTiled &t = s->tiled;
     static const uint32_t ablate = [] {
@@ -336,7 +347,7 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
 #define OEM_TILE(CH, REM, TH, MW, NC, UP)                                                          \
     hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP>), dim3(t.n_tiles), dim3(TH), 0,      \
                        s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot,             \
-                       t.queue, theta, cnt, state, row_w_perm, ablate)
+                       t.queue, theta, cnt, state, row_w_perm, ablate, problems)
     switch (variant) {
     case 1: OEM_TILE(8, 3, 512, 2, 4, true); break;   // all slices up front, 8 waves
     case 2: OEM_TILE(12, 6, 256, 2, 4, false); break;
@@ -348,7 +359,7 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
 }
 
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
-                         const uint32_t *row_w_perm)
+                         const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
@@ -358,10 +369,10 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     }();
     if (s->csr.w_is_f64)
         launch_tile_variant<double>(variant, s, (const double *)t.w64, (const double *)t.r_w64, theta,
-                                    cnt, state, row_w_perm);
+                                    cnt, state, row_w_perm, problems);
     else
         launch_tile_variant<float>(variant, s, (const float *)t.w32, (const float *)t.r_w32, theta, cnt,
-                                   state, row_w_perm);
+                                   state, row_w_perm, problems);
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
         // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
@@ -371,13 +382,15 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
             return e ? (uint32_t)atoi(e) : 256u;
         }();
         uint32_t n_groups = fold_wgs / (t.n_buckets ? t.n_buckets : 1);
+        // ... but every workgroup clears and flushes a whole 64 KiB window, which only pays for
+        // itself with >= 32 Ki queue entries to fold
         const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
-        const uint32_t max_useful = (uint32_t)((per_bucket + 4095) / 4096);
+        const uint32_t max_useful = (uint32_t)((per_bucket + 32767) / 32768);
         if (n_groups > max_useful) n_groups = max_useful;
         if (n_groups < 1) n_groups = 1;
         hipLaunchKernelGGL(k_remote_fold, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
                            s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                           s->csr.n_txps);
+                           s->csr.n_txps, problems, problem_size);
         OEM_HIP(hipGetLastError());
     }
     return OEM_OK;

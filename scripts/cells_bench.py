@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Times the batched per-cell EM against the one-cell-at-a-time path (OEM_SERIAL_CELLS=1)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oarfish_amd
+from oarfish_amd import synth
+n_cells, rpc, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+cell_off, row_ptr, tid, p = synth.make_cells(n_cells, rpc, T, seed=3)
+t = time.perf_counter()
+out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=1000, convergence_thresh=1e-3)
+dt = time.perf_counter() - t
+print(f"{'serial' if os.environ.get('OEM_SERIAL_CELLS') else 'batched'}: {n_cells} cells x {rpc} reads, T={T}: {dt:.3f} s "
+      f"({n_cells/dt:.1f} cells/s), mean passes {np.mean([i.n_passes for i in infos]):.0f}, sum {out.sum():.1f}")

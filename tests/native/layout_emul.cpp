@@ -11,11 +11,21 @@ using namespace oem;
 extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                                   const double *cov_prob, uint64_t n_reads, uint64_t nnz,
                                   uint32_t n_txps, const double *theta, const uint32_t *row_w,
-                                  double *cnt, uint64_t *stats /* n_tiles, n_local, n_remote, n_rows, w_slots */)
+                                  double *cnt, uint64_t *stats /* n_tiles, n_local, n_remote, n_rows, w_slots */,
+                                  uint32_t problem_size)
 {
     TiledHost h;
     const char *err = nullptr;
-    if (!build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err)) return 1;
+    if (!build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err, problem_size)) return 1;
+    if (problem_size) // a tile never mixes reads of two problems
+        for (uint32_t ti = 0; ti < h.n_tiles; ++ti) {
+            const TileDesc &td = h.tiles[ti];
+            for (uint32_t i = 0; i < td.n_rows; ++i) {
+                const uint32_t r = h.perm[td.row_base + i];
+                for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
+                    if (tid[j] / problem_size != td.problem) return 11;
+            }
+        }
     const bool f64 = cov_prob != nullptr;
     std::vector<double> queue(h.n_remote, -1.0);
     std::vector<uint8_t> slot_seen(h.n_remote, 0);

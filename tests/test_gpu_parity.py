@@ -206,6 +206,36 @@ def test_cells_match_per_cell_oracle():
         assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
 
 
+def test_cells_ragged_batch():
+    """Cells of very different sizes (incl. an empty one and a one-read one), with the coverage column:
+    every cell stops at its own iteration."""
+    T = 900
+    rng = np.random.default_rng(12)
+    sizes = [4000, 0, 1, 700, 2500, 60]
+    rps, tids, ps, covs = [np.zeros(1, np.uint64)], [], [], []
+    cell_off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    base = 0
+    for c, n in enumerate(sizes):
+        if n:
+            st = synth.make_store(n, T, seed=100 + c, coverage=True, threads=1)
+            rps.append(st.row_ptr[1:] + np.uint64(base)); tids.append(st.tid); ps.append(st.as_prob); covs.append(st.cov_prob)
+            base += st.nnz
+        cell_off[c + 1] = cell_off[c] + np.uint64(n)
+    row_ptr, tid, p, cov = np.concatenate(rps), np.concatenate(tids), np.concatenate(ps), np.concatenate(covs)
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, cov, T, max_iter=400, convergence_thresh=1e-3)
+    niters = []
+    for c, n in enumerate(sizes):
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        o = c_oracle.Store(row_ptr[r0:r1 + 1] - row_ptr[r0], tid[a0:a1], p[a0:a1], cov[a0:a1], T)
+        want, wi = c_oracle.do_em(o, max_iter=400, conv_thresh=1e-3, min_iter_gate=50)
+        assert abs(infos[c].niter - wi.niter) <= 1, (c, infos[c], wi)
+        assert_counts_close(out[c], want, max(n, 1), T, RTOL if infos[c].niter != wi.niter else 1e-8, f"cell {c}")
+        niters.append(wi.niter)
+    assert len(set(niters)) > 2
+    assert np.all(out[1] == 0.0)
+
+
 def test_edge_cases():
     # empty store: every count 0
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:

@@ -26,7 +26,7 @@ def emul():
     return C.CDLL(LIB)
 
 
-def _run(emul, row_ptr, tid, p, cov, T, theta, row_w=None):
+def _run(emul, row_ptr, tid, p, cov, T, theta, row_w=None, problem_size=0):
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
     tid = np.ascontiguousarray(tid, dtype=np.uint32)
     p = np.ascontiguousarray(p, dtype=np.float32)
@@ -34,7 +34,8 @@ def _run(emul, row_ptr, tid, p, cov, T, theta, row_w=None):
     stats = np.zeros(5, dtype=np.uint64)
     vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     rc = emul.layout_emul_m_step(vp(row_ptr), vp(tid), vp(p), vp(cov), C.c_uint64(len(row_ptr) - 1),
-                                 C.c_uint64(len(tid)), C.c_uint32(T), vp(theta), vp(row_w), vp(cnt), vp(stats))
+                                 C.c_uint64(len(tid)), C.c_uint32(T), vp(theta), vp(row_w), vp(cnt), vp(stats),
+                                 C.c_uint32(problem_size))
     assert rc == 0, f"layout self-check failed with code {rc}"
     return cnt, stats
 
@@ -79,3 +80,17 @@ def test_layout_empty_rows_and_sparse_keys(emul):
     got, stats = _run(emul, rp, tid, p, None, 50_000, theta)
     np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-12, atol=1e-14)
     assert int(stats[3]) == 3
+
+
+def test_layout_per_cell_problems(emul):
+    """Per-cell batch: cells concatenated over a virtual transcript space; tiles stay inside one cell."""
+    n_cells, T = 5, 700
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, 2_500, T, seed=3)
+    lens = np.diff(row_ptr.astype(np.int64))
+    cell_of_row = np.repeat(np.arange(n_cells), np.diff(cell_off.astype(np.int64)))
+    vtid = (tid.astype(np.int64) + np.repeat(cell_of_row, lens) * T).astype(np.uint32)
+    rng = np.random.default_rng(6)
+    theta = rng.lognormal(0, 1.5, size=n_cells * T)
+    o = c_oracle.Store(row_ptr, vtid, p, None, n_cells * T)
+    got, stats = _run(emul, row_ptr, vtid, p, None, n_cells * T, theta, problem_size=T)
+    np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-10, atol=1e-10)
