@@ -134,6 +134,21 @@ int oem_em_run(oem_store *store, const double *init_abundances, uint32_t max_ite
                oem_run_info *info);
 
 /* --------------------------------------------------------------------- */
+/* the steps right after the EM, on the same resident store                */
+/* --------------------------------------------------------------------- */
+
+/* aux_counts::get_aux_counts (src/util/aux_counts.rs:23-50): per transcript, the number of
+ * alignments (total) and the number of single-alignment reads (unique); n_txps u32 each. */
+int oem_aux_counts(oem_store *store, uint32_t *out_unique, uint32_t *out_total);
+
+/* The E-step of write_function::write_out_prob (src/util/write_function.rs:283-318): per read,
+ * nprob_j = clamp(counts[t_j]*p_j*cov_j / sum_j(...), 0, 1); alignments with nprob >=
+ * display_thresh are kept and renormalised by their sum.  out_prob is nnz f64 in the caller's
+ * alignment order: the probability the reference prints, or -1 for an alignment it omits. */
+int oem_assignment_probs(oem_store *store, const double *counts, double display_thresh,
+                         double *out_prob);
+
+/* --------------------------------------------------------------------- */
 /* bootstrap                                                              */
 /* --------------------------------------------------------------------- */
 

@@ -26,7 +26,7 @@ OEM_OPT_BATCH_BOOTSTRAP = 1
 ABI_SYMBOLS = [
     "oem_abi_version", "oem_last_error", "oem_device_count",
     "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_set_option",
-    "oem_m_step", "oem_em_run",
+    "oem_m_step", "oem_em_run", "oem_aux_counts", "oem_assignment_probs",
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
     "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_store_attach_comm",
@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
     L.oem_store_set_option.argtypes = [vp, u32, u64]
     L.oem_m_step.argtypes = [vp, vp, vp, vp]
     L.oem_em_run.argtypes = [vp, vp, u32, f64, u32, vp, C.POINTER(RunInfoC)]
+    L.oem_aux_counts.argtypes = [vp, vp, vp]
+    L.oem_assignment_probs.argtypes = [vp, vp, f64, vp]
     L.oem_bootstrap_weights.argtypes = [vp, u64, u32, vp]
     L.oem_bootstrap.argtypes = [vp, u32, u64, vp, vp, u32, f64, vp, vp]
     L.oem_em_run_cells.argtypes = [vp, u32, vp, vp, vp, vp, u64, u64, u32, i32, u32, f64, vp, vp]

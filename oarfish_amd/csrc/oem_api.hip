@@ -555,6 +555,49 @@ extern "C" int oem_em_run(oem_store *s, const double *init_abundances, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
+// the steps right after the EM
+// ---------------------------------------------------------------------------
+extern "C" int oem_aux_counts(oem_store *s, uint32_t *out_unique, uint32_t *out_total)
+{
+    if (!s || !out_unique || !out_total) return fail(OEM_ERR_ARG, "oem_aux_counts: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const uint32_t T = s->csr.n_txps;
+    uint32_t *d = nullptr;
+    OEM_TRY(dev_alloc(&d, 2 * (size_t)T, nullptr));
+    int rc = OEM_OK;
+    if (hipMemsetAsync(d, 0, sizeof(uint32_t) * 2 * T, s->stream) != hipSuccess) rc = fail(OEM_ERR_HIP, "oem_aux_counts: memset failed");
+    if (rc == OEM_OK) rc = launch_aux_counts(s, d, d + T);
+    if (rc == OEM_OK && (hipMemcpyAsync(out_unique, d, sizeof(uint32_t) * T, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                         hipMemcpyAsync(out_total, d + T, sizeof(uint32_t) * T, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                         hipStreamSynchronize(s->stream) != hipSuccess))
+        rc = fail(OEM_ERR_HIP, "oem_aux_counts: read-back failed");
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int oem_assignment_probs(oem_store *s, const double *counts, double display_thresh, double *out_prob)
+{
+    if (!s || !counts || (s->csr.nnz && !out_prob)) return fail(OEM_ERR_ARG, "oem_assignment_probs: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const uint32_t T = s->csr.n_txps;
+    const uint64_t nnz = s->csr.nnz;
+    double *d_out = nullptr;
+    OEM_TRY(dev_alloc(&d_out, nnz, nullptr));
+    int rc = OEM_OK;
+    if (hipMemcpyAsync(s->theta, counts, sizeof(double) * T, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+        rc = fail(OEM_ERR_HIP, "oem_assignment_probs: upload failed");
+    if (rc == OEM_OK) rc = launch_assignment_probs(s, s->theta, display_thresh, d_out);
+    if (rc == OEM_OK && nnz &&
+        (hipMemcpyAsync(out_prob, d_out, sizeof(double) * nnz, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+         hipStreamSynchronize(s->stream) != hipSuccess))
+        rc = fail(OEM_ERR_HIP, "oem_assignment_probs: read-back failed");
+    hipFree(d_out);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // bootstrap
 // ---------------------------------------------------------------------------
 extern "C" int oem_bootstrap_weights(oem_store *s, uint64_t seed, uint32_t replica, uint32_t *out_row_w)

@@ -212,6 +212,8 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p);
 int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg);
 int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow);
 
+int launch_aux_counts(oem_store *s, uint32_t *d_unique, uint32_t *d_total);
+int launch_assignment_probs(oem_store *s, const double *d_counts, double display_thresh, double *d_out);
 int launch_fill(oem_store *s, double *p, double v, uint64_t n);
 int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,
                              uint64_t n_global, uint64_t seed, uint32_t replica);

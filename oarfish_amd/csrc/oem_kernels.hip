@@ -175,6 +175,51 @@ __global__ __launch_bounds__(kBlock) void k_bootstrap_weights(uint32_t *row_w, u
     }
 }
 
+// aux_counts.rs:23-50
+template <typename PtrT>
+__global__ __launch_bounds__(kBlock) void k_aux_counts(const PtrT *__restrict__ row_ptr,
+                                                       const uint32_t *__restrict__ tid, uint64_t n_reads,
+                                                       uint32_t *unique_count, uint32_t *total_count)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        const bool is_unique = (e - b) == 1;                       // aux_counts.rs:35
+        for (uint64_t j = b; j < e; ++j) {
+            atomicAdd(&total_count[tid[j]], 1u);
+            if (is_unique) atomicAdd(&unique_count[tid[j]], 1u);
+        }
+    }
+}
+
+// write_function.rs:283-318, one lane per read over the caller-order CSR
+template <typename PtrT, typename WT>
+__global__ __launch_bounds__(kBlock) void k_assignment_probs(const PtrT *__restrict__ row_ptr,
+                                                             const uint32_t *__restrict__ tid,
+                                                             const WT *__restrict__ w,
+                                                             const double *__restrict__ counts,
+                                                             uint64_t n_reads, double display_thresh,
+                                                             double *__restrict__ out)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+        double denom = 0.0;
+        for (uint64_t j = b; j < e; ++j) denom += counts[tid[j]] * (double)w[j];       // :286-291
+        double denom2 = 0.0;
+        for (uint64_t j = b; j < e; ++j) {                                              // :303-314
+            double nprob = (counts[tid[j]] * (double)w[j]) / denom;
+            if (nprob < 0.0) nprob = 0.0;
+            if (nprob > 1.0) nprob = 1.0;                                               // clamp keeps NaN
+            const bool keep = nprob >= display_thresh;
+            out[j] = keep ? nprob : -1.0;
+            if (keep) denom2 += nprob;
+        }
+        for (uint64_t j = b; j < e; ++j)                                                // :316-318
+            if (out[j] >= 0.0) out[j] /= denom2;
+    }
+}
+
 inline int grid_for(uint64_t n, int block, int max_blocks)
 {
     uint64_t g = (n + block - 1) / block;
@@ -206,6 +251,41 @@ int launch_em_pass(oem_store *s, const double *theta, double *cnt, const EmState
         else OEM_LAUNCH_CSR(uint32_t, float, (const float *)m.w32);
     }
 #undef OEM_LAUNCH_CSR
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_aux_counts(oem_store *s, uint32_t *d_unique, uint32_t *d_total)
+{
+    const DeviceCsr &m = s->csr;
+    if (m.n_reads == 0) return OEM_OK;
+    const int grid = grid_for(m.n_reads, kBlock, 256 * 16);
+    if (m.wide_ptr)
+        hipLaunchKernelGGL((k_aux_counts<uint64_t>), dim3(grid), dim3(kBlock), 0, s->stream,
+                           (const uint64_t *)m.row_ptr, m.tid, m.n_reads, d_unique, d_total);
+    else
+        hipLaunchKernelGGL((k_aux_counts<uint32_t>), dim3(grid), dim3(kBlock), 0, s->stream,
+                           (const uint32_t *)m.row_ptr, m.tid, m.n_reads, d_unique, d_total);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_assignment_probs(oem_store *s, const double *d_counts, double display_thresh, double *d_out)
+{
+    const DeviceCsr &m = s->csr;
+    if (m.n_reads == 0) return OEM_OK;
+    const int grid = grid_for(m.n_reads, kBlock, 256 * 16);
+#define OEM_LAUNCH_AP(PT, WT, wptr)                                                                  \
+    hipLaunchKernelGGL((k_assignment_probs<PT, WT>), dim3(grid), dim3(kBlock), 0, s->stream,          \
+                       (const PT *)m.row_ptr, m.tid, wptr, d_counts, m.n_reads, display_thresh, d_out)
+    if (m.wide_ptr) {
+        if (m.w_is_f64) OEM_LAUNCH_AP(uint64_t, double, (const double *)m.w64);
+        else OEM_LAUNCH_AP(uint64_t, float, (const float *)m.w32);
+    } else {
+        if (m.w_is_f64) OEM_LAUNCH_AP(uint32_t, double, (const double *)m.w64);
+        else OEM_LAUNCH_AP(uint32_t, float, (const float *)m.w32);
+    }
+#undef OEM_LAUNCH_AP
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

@@ -135,6 +135,23 @@ class DeviceStore:
                                          out.ctypes.data, C.byref(ri)))
         return out, RunInfo(ri.niter, ri.n_passes, bool(ri.converged), ri.rel_diff)
 
+    def aux_counts(self):
+        """aux_counts.rs:23-50 -> (unique_count u32[T], total_count u32[T])."""
+        u = np.zeros(self.n_txps, dtype=np.uint32)
+        t = np.zeros(self.n_txps, dtype=np.uint32)
+        _lib.check(_lib.lib().oem_aux_counts(self.handle, u.ctypes.data, t.ctypes.data))
+        return u, t
+
+    def assignment_probs(self, counts, display_thresh: float) -> np.ndarray:
+        """write_function.rs:283-318: per-alignment printed probability, -1 where omitted."""
+        counts = np.ascontiguousarray(counts, dtype=np.float64)
+        if len(counts) != self.n_txps:
+            raise ValueError("counts length != n_txps")
+        out = np.zeros(self.nnz, dtype=np.float64)
+        _lib.check(_lib.lib().oem_assignment_probs(self.handle, counts.ctypes.data, display_thresh,
+                                                   out.ctypes.data))
+        return out
+
     def bootstrap_weights(self, seed: int, replica: int) -> np.ndarray:
         w = np.zeros(self.n_reads, dtype=np.uint32)
         _lib.check(_lib.lib().oem_bootstrap_weights(self.handle, seed, replica, w.ctypes.data))

@@ -188,6 +188,14 @@ def aux_counts(store: Store):
     return u, t
 
 
+def assignment_probs(store: Store, counts, display_thresh: float):
+    """write_function.rs:283-318; -1 marks an alignment that is not printed."""
+    counts = np.ascontiguousarray(counts, dtype=np.float64)
+    out = np.zeros(store.nnz, dtype=np.float64)
+    lib().oracle_assignment_probs(store.c, _p(counts), C.c_double(display_thresh), _p(out))
+    return out
+
+
 ALNINFO_DTYPE = np.dtype(
     [("prob", "<f8"), ("ref_id", "<u4"), ("start", "<u4"), ("end", "<u4"), ("strand", "u1")],
     align=True,

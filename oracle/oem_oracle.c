@@ -334,6 +334,41 @@ void oracle_aux_counts(const oracle_store *s, uint32_t *unique_count, uint32_t *
 }
 
 /* ------------------------------------------------------------------------ */
+/* write_function.rs:283-318                                                 */
+/* ------------------------------------------------------------------------ */
+void oracle_assignment_probs(const oracle_store *s, const double *counts, double display_thresh,
+                             double *out_prob)
+{
+    const int model_coverage = s->cov_prob != NULL;           /* write_function.rs:270 */
+    for (uint64_t i = 0; i < s->n_reads; ++i) {
+        const uint64_t b = s->row_ptr[i], e = s->row_ptr[i + 1];
+        double denom = 0.0;                                   /* :284 */
+        for (uint64_t j = b; j < e; ++j) {                    /* :286-291 */
+            const double prob = (double)s->as_prob[j];
+            const double cov = model_coverage ? s->cov_prob[j] : 1.0;
+            denom += counts[s->tid[j]] * prob * cov;
+        }
+        double denom2 = 0.0;                                  /* :301 */
+        for (uint64_t j = b; j < e; ++j) {                    /* :303-314 */
+            const double prob = (double)s->as_prob[j];
+            const double cov = model_coverage ? s->cov_prob[j] : 1.0;
+            double nprob = (counts[s->tid[j]] * prob * cov) / denom;
+            /* f64::clamp(0.0, 1.0): NaN stays NaN */
+            if (nprob < 0.0) nprob = 0.0;
+            if (nprob > 1.0) nprob = 1.0;
+            if (nprob >= display_thresh) {                    /* :309 (false for NaN) */
+                out_prob[j] = nprob;
+                denom2 += nprob;
+            } else {
+                out_prob[j] = -1.0;
+            }
+        }
+        for (uint64_t j = b; j < e; ++j)                      /* :316-318 */
+            if (out_prob[j] >= 0.0) out_prob[j] /= denom2;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* Reference-faithful 36 B/nnz layout (CPU baseline only)                    */
 _Static_assert(sizeof(oracle_alninfo) == 24, "AlnInfo is 24 bytes");
 /* ------------------------------------------------------------------------ */

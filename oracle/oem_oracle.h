@@ -96,6 +96,14 @@ int oracle_bootstrap(const oracle_store *s, const double *init, uint32_t n_boot,
  * alignments (total) and number of single-alignment reads (unique). */
 void oracle_aux_counts(const oracle_store *s, uint32_t *unique_count, uint32_t *total_count);
 
+/* src/util/write_function.rs:283-318 (write_out_prob, arithmetic only): per read,
+ * nprob_j = clamp(counts[t_j]*p_j*cov_j / denom, 0, 1); alignments with
+ * nprob >= display_thresh are kept and renormalised by their sum.  out_prob[j] is the
+ * renormalised probability, or -1 for an alignment that is not printed.  (The KDE
+ * factor is not part of this computation in the reference either.) */
+void oracle_assignment_probs(const oracle_store *s, const double *counts, double display_thresh,
+                             double *out_prob);
+
 /* ---- reference-faithful memory layout, for the CPU baseline only ----------
  * AlnInfo is {ref_id u32, start u32, end u32, prob f64, strand u8}
  * (oarfish_types.rs:330-337) = 24 B with natural alignment; the reference

@@ -236,6 +236,34 @@ def test_cells_ragged_batch():
     assert np.all(out[1] == 0.0)
 
 
+@pytest.mark.parametrize("coverage", [False, True])
+def test_aux_counts_and_assignment_probs(coverage):
+    """The two steps right after the EM on the same resident store:
+    aux_counts.rs:23-50 (integers: bit-exact) and the E-step of write_out_prob
+    (write_function.rs:283-318; f64, same operation order: 1e-12)."""
+    st = synth.make_store(40_000, 3_000, seed=91, coverage=coverage)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps) as d:
+        u, t = d.aux_counts()
+        wu, wt = c_oracle.aux_counts(o)
+        assert np.array_equal(u, wu) and np.array_equal(t, wt)
+        counts, _ = d.em_run(None, 120, 1e-3, 50)
+        for thresh in (0.0, 1e-3, 0.2):
+            got = d.assignment_probs(counts, thresh)
+            want = c_oracle.assignment_probs(o, counts, thresh)
+            assert np.array_equal(got < 0, want < 0), f"kept sets differ at thresh {thresh}"
+            k = want >= 0
+            np.testing.assert_allclose(got[k], want[k], rtol=1e-12, atol=0)
+            s = np.add.reduceat(np.where(k, got, 0.0), st.row_ptr[:-1].astype(np.int64))
+            kept_rows = np.add.reduceat(k.astype(np.int64), st.row_ptr[:-1].astype(np.int64)) > 0
+            np.testing.assert_allclose(s[kept_rows], 1.0, rtol=1e-12)   # renormalised per read
+    # a read none of whose transcripts has mass: denom = 0 -> nothing printed (NaN >= thresh is false)
+    rp = np.array([0, 2, 3], dtype=np.uint64)
+    with DeviceStore(rp, np.array([0, 1, 2], np.uint32), np.array([1.0, 0.5, 1.0], np.float32), None, 3) as d:
+        got = d.assignment_probs(np.array([0.0, 0.0, 4.0]), 1e-3)
+    assert np.all(got[:2] == -1.0) and got[2] == 1.0
+
+
 def test_edge_cases():
     # empty store: every count 0
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:

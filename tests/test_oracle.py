@@ -147,3 +147,16 @@ def test_sample_inds_distribution():
     assert abs((w == 0).mean() - np.exp(-1)) < 0.02
     assert not np.array_equal(inds, c_oracle.get_sample_inds(n, 124))
     assert np.array_equal(inds, c_oracle.get_sample_inds(n, 123))
+
+
+def test_assignment_probs_closed_form():
+    """write_function.rs:283-318 on a hand-checkable read."""
+    rp = np.array([0, 3, 4], dtype=np.uint64)
+    tid = np.array([0, 1, 2, 1], dtype=np.uint32)
+    p = np.array([1.0, 1.0, 0.5, 1.0], dtype=np.float32)
+    s = c_oracle.Store(rp, tid, p, None, 3)
+    counts = np.array([6.0, 3.0, 2.0])          # read 0: 6, 3, 1 -> 0.6, 0.3, 0.1
+    out = c_oracle.assignment_probs(s, counts, 0.2)
+    np.testing.assert_allclose(out, [0.6 / 0.9, 0.3 / 0.9, -1.0, 1.0], rtol=1e-15)
+    out0 = c_oracle.assignment_probs(s, counts, 0.0)
+    np.testing.assert_allclose(out0, [0.6, 0.3, 0.1, 1.0], rtol=1e-15)
