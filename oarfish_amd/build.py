@@ -54,6 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip"]
+    if os.environ.get("OEM_TILE_ABLATION"):  # profiling builds only: enables the OEM_TILE_ABLATE switches
+        cmd.append("-DOEM_TILE_ABLATION")
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp", "-ldl"]
     if verbose:

@@ -155,9 +155,15 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
-    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate,
+    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate_arg,
     const BatchState *__restrict__ problems)
 {
+#ifdef OEM_TILE_ABLATION // timing experiments only (profiles/r01_notes.md); never in a product build
+    const uint32_t ablate = ablate_arg;
+#else
+    constexpr uint32_t ablate = 0;
+    (void)ablate_arg;
+#endif
     if (state && state->done) return;
 
     __shared__ double theta_l[kWin];
@@ -340,10 +346,14 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
                                 const uint32_t *row_w_perm, const BatchState *problems)
 {
     const DeviceTiled &t = s->tiled;
+#ifdef OEM_TILE_ABLATION
     static const uint32_t ablate = [] {
         const char *e = getenv("OEM_TILE_ABLATE"); // timing experiments only: results are wrong when set
         return e ? (uint32_t)atoi(e) : 0u;
     }();
+#else
+    constexpr uint32_t ablate = 0;
+#endif
 #define OEM_TILE(CH, REM, TH, MW, NC, UP)                                                          \
     hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP>), dim3(t.n_tiles), dim3(TH), 0,      \
                        s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot,             \
