@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "tiny"])
     ap.add_argument("--bootstraps", type=int, default=2, help="bootstrap replicates to time (0 = skip)")
-    ap.add_argument("--batch-bootstrap", action="store_true", help="4 replicates per pass (experimental)")
+    ap.add_argument("--no-batch-bootstrap", action="store_true", help="one replicate per pass instead of two")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -196,8 +196,8 @@ def main():
     # bootstraps/sec (each = one resampled EM to convergence, em.rs:273-290)
     boots = None
     if args.bootstraps > 0:
-        if args.batch_bootstrap:
-            store.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 1)
+        if args.no_batch_bootstrap:
+            store.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
         sync()
         tb = time.perf_counter()
         _out, infos = store.bootstrap(args.bootstraps, seed=1, max_iter=1000, conv_thresh=1e-3)

@@ -96,8 +96,8 @@ void oem_store_destroy(oem_store *store);
 /* Tuning switches of a store (not part of the reference's semantics; results are
  * unchanged up to floating-point summation order). */
 typedef enum {
-    OEM_OPT_BATCH_BOOTSTRAP = 1 /* value 1: oem_bootstrap runs 4 replicates per pass over the matrix
-                                   (default 0: one replicate per pass, currently the faster form) */
+    OEM_OPT_BATCH_BOOTSTRAP = 1 /* value 1 (default): oem_bootstrap runs 2 replicates per pass over the
+                                   matrix when it can (f32 weights, multiplicities < 256); 0: one per pass */
 } oem_option;
 int oem_store_set_option(oem_store *store, uint32_t option, uint64_t value);
 

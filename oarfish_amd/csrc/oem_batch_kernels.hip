@@ -10,7 +10,7 @@
 //
 // Every replicate keeps its own loop state on the device and walks the reference's
 // state machine by itself: RUNNING -(stopping rule em.rs:212 / max_iter em.rs:181)->
-// FINAL (theta < 1e-5 zeroed, em.rs:238-242; one more pass, em.rs:245-252) ->
+// FINAL (theta < 1e-5 read as 0, em.rs:238-242; one more pass, em.rs:245-252) ->
 // FINISHED (counts parked in `out`, replicate ignored from then on).
 #include <cstdlib>
 
@@ -21,11 +21,7 @@ namespace oem {
 namespace {
 
 constexpr int kB = kBatch;
-constexpr int kBThreads = 512;
-constexpr int kBWaves = kBThreads / 64;
-constexpr int kBPerWave = kTileSlices / kBWaves; // 2 slices per wavefront
-constexpr int kBCh = 8;                          // alignments per read kept in registers
-constexpr int kBRem = 3;                         // remote alignments per thread kept in registers
+constexpr int kBCh = 8;     // alignments per read kept in registers
 constexpr int kFoldThreadsB = 1024;
 
 __device__ __forceinline__ void lds_add(double *p, double v)
@@ -56,8 +52,12 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restr
     }
 }
 
-// active[b] != 0 <=> replicate b still takes part in this pass (RUNNING or FINAL)
-__global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
+// Same structure as k_em_tile (oem_tile_kernels.hip): one workgroup per tile, one read per
+// lane, slices prefetched one ahead, operands landed with one counted wait, count window in
+// kCopies interleaved copies -- with every LDS / queue / theta entity carrying kB replicates.
+// Window entry (c, b, copy p) lives at ((c * kB + b) * kCopies + p).
+template <int kThreads, int kRem, int kCopies, int kMinWaves>
+__global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const float *__restrict__ w, const uint32_t *__restrict__ r_tid, const float *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
@@ -65,81 +65,94 @@ __global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
 {
-    uint32_t act = 0;
+    uint32_t act = 0; // replicates that still take part in this pass (RUNNING or FINAL)
+    uint32_t fin = 0; // replicates on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
 #pragma unroll
-    for (int b = 0; b < kB; ++b) act |= (st[b].phase != kPhaseFinished) ? (1u << b) : 0u;
+    for (int b = 0; b < kB; ++b) {
+        const uint32_t ph = st[b].phase;
+        act |= (ph != kPhaseFinished) ? (1u << b) : 0u;
+        fin |= (ph == kPhaseFinal) ? (1u << b) : 0u;
+    }
     if (!act) return;
+    auto th = [&](double v, int b) -> double {
+        return (((fin >> b) & 1u) && v < OEM_MIN_READ_THRESH) ? 0.0 : v;
+    };
 
     __shared__ double theta_l[kWin * kB];
-    __shared__ double cnt_l[kWin * kB];
+    __shared__ double cnt_l[kWin * kB * kCopies];
     __shared__ double den_l[kTileRows * kB];
 
+    constexpr uint32_t kWaves = kThreads / 64;
+    constexpr uint32_t kPerWave = kTileSlices / kWaves;
     const TileDesc td = tiles[blockIdx.x];
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);
+    const uint32_t copy = lane % kCopies;
 
-    uint32_t woff[kBPerWave], coff[kBPerWave], wid[kBPerWave];
+    uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
     {
         uint32_t accw = td.w_base, accc = td.c_base;
 #pragma unroll
         for (uint32_t i = 0; i < kTileSlices; ++i) {
             const uint32_t wi = td.width[i];
-            if ((i % kBWaves) == wave) {
-                woff[i / kBWaves] = accw;
-                coff[i / kBWaves] = accc;
-                wid[i / kBWaves] = wi;
+            if ((i % kWaves) == wave) {
+                woff[i / kWaves] = accw;
+                coff[i / kWaves] = accc;
+                wid[i / kWaves] = wi;
             }
             accw += wi;
             accc += (wi + 1) >> 1;
         }
     }
-    SliceRegsB R[kBPerWave];
-#pragma unroll
-    for (uint32_t q = 0; q < kBPerWave; ++q)
-        load_slice_b(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
 
-    // remote alignments of this thread: x[b] = theta[t][b] * w
-    double rx[kBRem][kB];
-    uint32_t rrow[kBRem], rslot[kBRem];
+    // remote alignments of this thread: x[b] = theta[t][b] * w (one 16-byte access serves both replicates)
+    double rx[kRem][kB];
+    uint32_t rrow[kRem], rslot[kRem];
+    {
+        uint32_t rt[kRem];
+        float rw[kRem];
 #pragma unroll
-    for (int k = 0; k < kBRem; ++k) {
-        const uint32_t i = tx + k * kBThreads;
-        rrow[k] = 0;
-        rslot[k] = 0;
+        for (int k = 0; k < kRem; ++k) {
+            const uint32_t i = tx + k * kThreads;
+            rt[k] = 0; rw[k] = 0.f; rrow[k] = 0; rslot[k] = 0;
+            if (i < td.remote_cnt) {
+                const uint32_t o = td.remote_begin + i;
+                rt[k] = r_tid[o];
+                rw[k] = r_w[o];
+                rrow[k] = r_row[o];
+                rslot[k] = r_slot[o];
+            }
+        }
 #pragma unroll
-        for (int b = 0; b < kB; ++b) rx[k][b] = 0.0;
-        if (i < td.remote_cnt) {
-            const uint32_t o = td.remote_begin + i;
-            const uint32_t t = r_tid[o];
-            const double wv = (double)r_w[o];
-            rrow[k] = r_row[o];
-            rslot[k] = r_slot[o];
+        for (int k = 0; k < kRem; ++k) {
 #pragma unroll
-            for (int b = 0; b < kB; ++b) rx[k][b] = theta[(size_t)t * kB + b] * wv;
+            for (int b = 0; b < kB; ++b) rx[k][b] = th(theta[(size_t)rt[k] * kB + b], b) * (double)rw[k];
         }
     }
-    for (uint32_t i = tx; i < td.win_len * kB; i += kBThreads) {
-        theta_l[i] = theta[(size_t)td.lo * kB + i];
-        cnt_l[i] = 0.0;
-    }
-    for (uint32_t i = tx; i < td.n_slices * 64 * kB; i += kBThreads) den_l[i] = 0.0;
+    constexpr uint32_t kSets = kPerWave > 1 ? 2 : 1;
+    SliceRegsB R[kSets];
+    load_slice_b(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+
+    for (uint32_t i = tx; i < td.win_len * kB; i += kThreads) theta_l[i] = th(theta[(size_t)td.lo * kB + i], i % kB);
+    for (uint32_t i = tx; i < td.win_len * kB * kCopies; i += kThreads) cnt_l[i] = 0.0;
+    for (uint32_t i = tx; i < td.n_slices * 64 * kB; i += kThreads) den_l[i] = 0.0;
     __syncthreads();
 
     // remote phase A: denominators
 #pragma unroll
-    for (int k = 0; k < kBRem; ++k)
-        if (tx + k * kBThreads < td.remote_cnt) {
+    for (int k = 0; k < kRem; ++k)
+        if (tx + k * kThreads < td.remote_cnt) {
 #pragma unroll
             for (int b = 0; b < kB; ++b) lds_add(&den_l[rrow[k] * kB + b], rx[k][b]);
         }
-    for (uint32_t i = tx + kBRem * kBThreads; i < td.remote_cnt; i += kBThreads) { // overflow: park in the queue
+    for (uint32_t i = tx + kRem * kThreads; i < td.remote_cnt; i += kThreads) { // overflow: park in the queue
         const uint32_t o = td.remote_begin + i;
         const uint32_t t = r_tid[o];
         const double wv = (double)r_w[o];
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
-            const double x = theta[(size_t)t * kB + b] * wv;
+            const double x = th(theta[(size_t)t * kB + b], b) * wv;
             queue[(size_t)b * n_remote + r_slot[o]] = x;
             lds_add(&den_l[r_row[o] * kB + b], x);
         }
@@ -148,29 +161,42 @@ __global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
 
     // local alignments
 #pragma unroll
-    for (uint32_t q = 0; q < kBPerWave; ++q) {
-        const uint32_t s = wave + kBWaves * q;
+    for (uint32_t q = 0; q < kPerWave; ++q) {
+        const uint32_t s = wave + kWaves * q;
+        if (q + 1 < kPerWave)
+            load_slice_b(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+                         wid[q + 1]);
         if (s >= td.n_slices) continue;
+        const SliceRegsB &cur = R[q % kSets];
+        // land this slice's operands with one counted wait (the next slice's loads stay in flight)
+#pragma unroll
+        for (int k = 0; k < kBCh; ++k) asm volatile("" ::"v"(cur.w[k]));
+#pragma unroll
+        for (int k = 0; k < kBCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
         const uint32_t width = wid[q];
         const uint32_t rl = s * 64 + lane;
         const float *wbase = w + (size_t)woff[q] * 64;
         const uint32_t *cbase = codes + (size_t)coff[q] * 64;
         uint32_t mult = 0; // packed multiplicities of this read, one byte per replicate
-        if (rl < td.n_rows) mult = *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB);
+        if (rl < td.n_rows) {
+            const uint8_t *mp = row_w + (size_t)(td.row_base + rl) * kB;
+#pragma unroll
+            for (int b = 0; b < kB; ++b) mult |= (uint32_t)mp[b] << (8 * b);
+        }
         double inv[kB];
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
             double denom = den_l[rl * kB + b];
 #pragma unroll
             for (int k = 0; k < kBCh; ++k) {
-                const uint32_t off = (k & 1) ? (R[q].c[k >> 1] >> 16) : (R[q].c[k >> 1] & 0xffffu);
-                const double wk = (uint32_t)k < width ? (double)R[q].w[k] : 0.0;
-                denom += theta_l[(off >> 3) * kB + b] * wk;                     // em.rs:111
+                const uint32_t c = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) >> 3;
+                const double wk = (uint32_t)k < width ? (double)cur.w[k] : 0.0;
+                denom += theta_l[c * kB + b] * wk;                               // em.rs:111
             }
             for (uint32_t j = kBCh; j < width; ++j) {
                 const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-                const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
-                denom += theta_l[(off >> 3) * kB + b] * (double)wbase[j * 64 + lane];
+                const uint32_t c = ((j & 1) ? (cc >> 16) : (cc & 0xffffu)) >> 3;
+                denom += theta_l[c * kB + b] * (double)wbase[j * 64 + lane];
             }
             const double scale = (double)((mult >> (8 * b)) & 0xffu);
             inv[b] = ((act >> b) & 1u) && denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0; // em.rs:115
@@ -179,23 +205,23 @@ __global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             if ((uint32_t)k < width) {
-                const uint32_t off = (k & 1) ? (R[q].c[k >> 1] >> 16) : (R[q].c[k >> 1] & 0xffffu);
-                const double wk = (double)R[q].w[k];
+                const uint32_t c = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) >> 3;
+                const double wk = (double)cur.w[k];
 #pragma unroll
                 for (int b = 0; b < kB; ++b) {
-                    const double v = theta_l[(off >> 3) * kB + b] * wk * inv[b];
-                    if (v != 0.0) lds_add(&cnt_l[(off >> 3) * kB + b], v);      // em.rs:128-129
+                    const double v = theta_l[c * kB + b] * wk * inv[b];
+                    if (v != 0.0) lds_add(&cnt_l[(c * kB + b) * kCopies + copy], v); // em.rs:128-129
                 }
             }
         }
         for (uint32_t j = kBCh; j < width; ++j) {
             const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-            const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+            const uint32_t c = ((j & 1) ? (cc >> 16) : (cc & 0xffffu)) >> 3;
             const double wk = (double)wbase[j * 64 + lane];
 #pragma unroll
             for (int b = 0; b < kB; ++b) {
-                const double v = theta_l[(off >> 3) * kB + b] * wk * inv[b];
-                if (v != 0.0) lds_add(&cnt_l[(off >> 3) * kB + b], v);
+                const double v = theta_l[c * kB + b] * wk * inv[b];
+                if (v != 0.0) lds_add(&cnt_l[(c * kB + b) * kCopies + copy], v);
             }
         }
     }
@@ -203,15 +229,15 @@ __global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
 
     // remote phase B: queue[b][slot] <- x_b * (c_ib / denom_ib)
 #pragma unroll
-    for (int k = 0; k < kBRem; ++k) {
-        const uint32_t i = tx + k * kBThreads;
+    for (int k = 0; k < kRem; ++k) {
+        const uint32_t i = tx + k * kThreads;
         if (i < td.remote_cnt) {
 #pragma unroll
             for (int b = 0; b < kB; ++b)
                 queue[(size_t)b * n_remote + rslot[k]] = rx[k][b] * den_l[rrow[k] * kB + b];
         }
     }
-    for (uint32_t i = tx + kBRem * kBThreads; i < td.remote_cnt; i += kBThreads) {
+    for (uint32_t i = tx + kRem * kThreads; i < td.remote_cnt; i += kThreads) {
         const uint32_t o = td.remote_begin + i;
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
@@ -220,8 +246,10 @@ __global__ __launch_bounds__(kBThreads, 2) void k_em_tile_b(
         }
     }
     // flush: the window is contiguous in [T][kB]
-    for (uint32_t i = tx; i < td.win_len * kB; i += kBThreads) {
-        const double v = cnt_l[i];
+    for (uint32_t i = tx; i < td.win_len * kB; i += kThreads) {
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
         if (v != 0.0) unsafeAtomicAdd(&cnt[(size_t)td.lo * kB + i], v);
     }
 }
@@ -356,27 +384,6 @@ __global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, d
     }
 }
 
-// em.rs:238-242 for the replicates that just entered FINAL (needs_zero set by the host-side
-// bookkeeping kernel below is avoided: the flag lives in the state and is cleared here)
-__global__ __launch_bounds__(256) void k_zero_small_b(double *__restrict__ theta, BatchState *st, uint32_t n_txps)
-{
-    uint32_t z = 0;
-#pragma unroll
-    for (int b = 0; b < kB; ++b)
-        if (st[b].phase == kPhaseFinal && !st[b].zeroed) z |= 1u << b;
-    if (!z) return;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int b = 0; b < kB; ++b)
-            if (((z >> b) & 1u) && theta[(size_t)i * kB + b] < OEM_MIN_READ_THRESH) theta[(size_t)i * kB + b] = 0.0;
-    }
-}
-__global__ void k_mark_zeroed_b(BatchState *st)
-{
-    const int b = threadIdx.x;
-    if (b < kB && st[b].phase == kPhaseFinal) st[b].zeroed = 1;
-}
-
 // theta[t][b] = value (uniform init) or init[t]
 __global__ __launch_bounds__(256) void k_init_theta_b(double *__restrict__ theta, const double *__restrict__ init,
                                                       double avg, uint32_t n_txps)
@@ -398,14 +405,12 @@ __global__ __launch_bounds__(256) void k_pack_row_w_b(const uint32_t *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = perm[i];
-        uint32_t packed = 0;
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
             const uint32_t c = row_w[(uint64_t)b * n_reads + r];
             if (c > 255u) *overflow = 1u;
-            packed |= (c & 0xffu) << (8 * b);
+            out[i * kB + b] = (uint8_t)(c & 0xffu);
         }
-        *reinterpret_cast<uint32_t *>(out + i * kB) = packed;
     }
 }
 
@@ -423,9 +428,22 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    hipLaunchKernelGGL(k_em_tile_b, dim3(t.n_tiles), dim3(kBThreads), 0, s->stream, t.tiles, t.codes,
-                       (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
-                       t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
+    static const int variant = [] {
+        const char *e = getenv("OEM_BATCH_VARIANT"); // tuning knob
+        return e ? atoi(e) : 0;
+    }();
+#define OEM_TILE_B(TH, REM, NC, MW)                                                                       \
+    hipLaunchKernelGGL((k_em_tile_b<TH, REM, NC, MW>), dim3(t.n_tiles), dim3(TH), 0, s->stream, t.tiles,    \
+                       t.codes, (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot,   \
+                       bb.queue, t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
+    switch (variant) {
+    case 1: OEM_TILE_B(256, 6, 4, 2); break;
+    case 2: OEM_TILE_B(512, 3, 2, 2); break;
+    case 3: OEM_TILE_B(512, 3, 4, 2); break;
+    case 4: OEM_TILE_B(256, 6, 1, 2); break;
+    default: OEM_TILE_B(256, 6, 2, 2); break;
+    }
+#undef OEM_TILE_B
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);
@@ -446,9 +464,7 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
     const int grid = grid_for(p.n_txps, 256, 256);
     hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
-    // replicates that just entered FINAL get their small abundances zeroed before the next pass
-    hipLaunchKernelGGL(k_zero_small_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.state, p.n_txps);
-    hipLaunchKernelGGL(k_mark_zeroed_b, dim3(1), dim3(64), 0, s->stream, bb.state);
+    // (a replicate on its FINAL pass reads theta < 1e-5 as 0 inside k_em_tile_b: em.rs:238-242)
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

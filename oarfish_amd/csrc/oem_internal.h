@@ -109,7 +109,7 @@ struct DeviceTiled {
 // (oem_batch_kernels.hip).  Per-replicate loop state, walked on the device:
 // RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
-constexpr int kBatch = 4;
+constexpr int kBatch = 2;
 enum : uint32_t { kPhaseRunning = 0, kPhaseFinal = 1, kPhaseFinished = 2 };
 
 struct BatchState {
@@ -169,7 +169,7 @@ struct oem_store {
     double *h_pinned = nullptr;          // pinned staging, n_txps f64
     oem::BatchBuffers batch;             // lazily allocated by the batched bootstrap
     oem::MultiBuffers multi;             // per-cell batches
-    bool batch_bootstrap = false;        // OEM_OPT_BATCH_BOOTSTRAP
+    bool batch_bootstrap = true;         // OEM_OPT_BATCH_BOOTSTRAP (2 replicates per pass when applicable)
     // multi-GPU
     oem::Comm *comm = nullptr;
     uint64_t global_n_reads = 0;
