@@ -181,3 +181,46 @@ def make_cells(n_cells: int, reads_per_cell: int, n_txps: int, kbar: float = 8.0
         cell_off[c + 1] = cell_off[c] + np.uint64(st.n_reads)
     return (cell_off, np.concatenate(rps), np.concatenate(tids) if tids else np.zeros(0, np.uint32),
             np.concatenate(ps) if ps else np.zeros(0, np.float32))
+
+
+def make_sirv_store(tag: str = "C", n_reads: int = 20_000, seed: int = BASE_SEED + 1,
+                    coverage: bool = False, table_path: Optional[str] = None) -> SyntheticStore:
+    """BASELINE config[0] stand-in: a SIRV-shaped store (T = 69 / 44 / 100 for the C / I / O
+    annotations).  The reference's test_data has no BAM or reads, so reads are synthesised over
+    the real SIRV isoform structure (tests/golden/sirv_txps.json: gene, length and pairwise exonic
+    overlap of every transcript, derived from the reference's GTFs by scripts/make_sirv_fixture.py):
+    a read's primary is drawn from a log-normal mix; every isoform of the same gene that shares
+    exonic sequence with it is a secondary alignment with probability overlap/length, scored with
+    a deficit that grows as the overlap shrinks."""
+    import json
+    import os
+    if table_path is None:
+        table_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                  "tests", "golden", "sirv_txps.json")
+    tab = json.load(open(table_path))[tag]
+    T = len(tab["names"])
+    length = np.asarray(tab["length"], dtype=np.float64)
+    ov = np.zeros((T, T))
+    for k, v in tab["overlap"].items():
+        i, j = (int(x) for x in k.split(","))
+        ov[i, j] = ov[j, i] = v
+    rng = np.random.default_rng([seed, ord(tag)])
+    a = rng.lognormal(0.0, 1.5, size=T)
+    a /= a.sum()
+    t0 = rng.choice(T, size=n_reads, p=a)
+    frac = np.clip(ov[t0] / length[t0][:, None], 0.0, 1.0)         # [n_reads, T]
+    take = rng.random((n_reads, T)) < frac
+    take[np.arange(n_reads), t0] = True
+    d = np.minimum(np.floor((1.0 - frac) * 12.0) + rng.geometric(0.3, size=(n_reads, T)) - 1, 60)
+    d[np.arange(n_reads), t0] = 0
+    rows, cols = np.nonzero(take)
+    p = np.exp((-d[rows, cols].astype(np.float32)) / np.float32(5.0)).astype(np.float32)
+    lens = np.bincount(rows, minlength=n_reads).astype(np.uint64)
+    row_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(lens, out=row_ptr[1:])
+    cov = None
+    if coverage:
+        cov = rng.uniform(0.05, 1.0, size=len(cols))
+        ssum = np.add.reduceat(cov, row_ptr[:-1].astype(np.int64))
+        cov = cov / np.repeat(ssum, lens.astype(np.int64))
+    return SyntheticStore(row_ptr, cols.astype(np.uint32), p, cov, T, a, np.asarray(tab["gene"], dtype=np.int32))

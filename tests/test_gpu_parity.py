@@ -290,6 +290,47 @@ def test_edge_cases():
         assert_counts_close(cnt, g["runs"][0]["counts"], 1500, 200, 1e-10, "max_iter 0")
 
 
+@pytest.mark.parametrize("tag", ["C", "I", "O"])
+def test_config0_sirv_shaped_store(tag):
+    """BASELINE configs[0] on the device: SIRV annotation (69 / 44 / 100 transcripts), bulk mode,
+    100 EM iterations, with and without the coverage column."""
+    for coverage in (False, True):
+        st = synth.make_sirv_store(tag, 20_000, coverage=coverage)
+        o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+        want, wi = c_oracle.do_em(o, max_iter=100, conv_thresh=0.0)
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps) as d:
+            got, gi = d.em_run(None, 100, 0.0, 50)
+            par, pi = d.em_run(None, 1000, 1e-3, 1)
+        assert gi.niter == wi.niter == 100 and gi.n_passes == 101
+        assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, f"SIRV {tag} cov={coverage}")
+        wpar, wpi = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=1)
+        assert abs(pi.niter - wpi.niter) <= 1
+        assert_counts_close(par, wpar, st.n_reads, st.n_txps, RTOL, f"SIRV {tag} em_par cov={coverage}")
+
+
+def test_full_size_c3_properties():
+    """BASELINE configs[2] (10 M reads x 200 k transcripts, ~80 M alignments) on one GPU:
+    size-independent properties, plus parity with the multi-threaded oracle over a short fixed
+    number of iterations (the oracle needs ~0.15 s per pass at this size)."""
+    st = synth.make_config("c3")
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    u, t = c_oracle.aux_counts(o)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        du, dt = d.aux_counts()
+        assert np.array_equal(du, u) and np.array_equal(dt, t)                # integer work: bit-exact
+        cnt, info = d.em_run(None, 12, 0.0, 50)
+        assert info.niter == 12 and info.n_passes == 13
+        assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads                # mass conservation
+        assert np.all(cnt >= u - 1e-6) and np.all(cnt <= t + 1e-6)            # unique <= count <= total
+        want, wi = c_oracle.em_par(o, max_iter=12, conv_thresh=0.0, min_iter_gate=50)
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, 1e-8, "c3, 12 iterations")
+        full, finfo = d.em_run(None, 1000, 1e-3, 1)                           # em_par semantics to convergence
+        assert abs(full.sum() - st.n_reads) < 1e-7 * st.n_reads
+        assert np.all(full >= u - 1e-6) and np.all(full <= t + 1e-6)
+        w = d.bootstrap_weights(3, 0)
+        assert int(w.sum()) == st.n_reads and abs(w.var() - 1.0) < 0.01
+
+
 @pytest.mark.parametrize("name", ["c2"])
 def test_full_size_properties(name):
     """BASELINE configs[1] (1M reads x 60k txps): size-independent properties + fixed-iteration

@@ -160,3 +160,20 @@ def test_assignment_probs_closed_form():
     np.testing.assert_allclose(out, [0.6 / 0.9, 0.3 / 0.9, -1.0, 1.0], rtol=1e-15)
     out0 = c_oracle.assignment_probs(s, counts, 0.0)
     np.testing.assert_allclose(out0, [0.6, 0.3, 0.1, 1.0], rtol=1e-15)
+
+
+@pytest.mark.parametrize("tag,T", [("C", 69), ("I", 44), ("O", 100)])
+def test_config0_sirv_shaped_store_cpu(tag, T):
+    """BASELINE configs[0]: SIRV annotation, bulk mode, 100 EM iterations on the CPU path (plumbing):
+    C restatement == NumPy restatement; mass conserved; unique <= count <= total."""
+    from oarfish_amd import synth
+    st = synth.make_sirv_store(tag, 20_000)
+    assert st.n_txps == T and st.n_reads == 20_000 and np.diff(st.row_ptr.astype(np.int64)).min() >= 1
+    s = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    a, ia = c_oracle.do_em(s, max_iter=100, conv_thresh=0.0)
+    b, niter, npass, conv, rel = oracle_np.do_em(st.row_ptr, st.tid, st.as_prob, None, T, max_iter=100, conv_thresh=0.0)
+    assert ia.niter == niter == 100 and ia.n_passes == npass == 101 and not conv
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-10)
+    assert abs(a.sum() - st.n_reads) < 1e-8
+    u, t = c_oracle.aux_counts(s)
+    assert np.all(a >= u - 1e-9) and np.all(a <= t + 1e-9)
