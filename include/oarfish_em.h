@@ -66,7 +66,10 @@ typedef struct {
 /* Layout / tuning knobs of a store (all optional; zero = default). */
 typedef struct {
     uint32_t reorder_rows; /* 0 = default (locality reorder on), 1 = keep caller order, 2 = force reorder */
-    uint32_t reserved[7];
+    uint32_t problem_size; /* 0 = one EM problem; > 0: the transcript space is the concatenation of
+                              independent problems of this many transcripts (tiles never mix them);
+                              set by oem_em_run_cells for its per-cell batches */
+    uint32_t reserved[6];
 } oem_store_opts;
 
 /* --------------------------------------------------------------------- */

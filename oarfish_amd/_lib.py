@@ -51,7 +51,7 @@ class RunInfoC(C.Structure):
 
 
 class StoreOptsC(C.Structure):
-    _fields_ = [("reorder_rows", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+    _fields_ = [("reorder_rows", C.c_uint32), ("problem_size", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 _lib = None

@@ -364,8 +364,6 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     return OEM_OK;
 }
 
-thread_local uint32_t t_problem_size = 0; // set by oem_em_run_cells around its store creation
-
 int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                       const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
                       int device, const oem_store_opts *opts, oem_store *s)
@@ -418,7 +416,8 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     if (reorder != 1 && n_reads > 0) {
         TiledHost h;
         const char *err = nullptr;
-        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err, t_problem_size)) {
+        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
+                               opts ? opts->problem_size : 0u)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
             return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
@@ -687,13 +686,12 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
         }
     }
     oem_store *s = nullptr;
-    t_problem_size = n_txps;
     oem_store_opts opts;
     std::memset(&opts, 0, sizeof(opts));
     opts.reorder_rows = 2;
+    opts.problem_size = n_txps;
     int rc = oem_store_create(row_ptr, vt.data(), as_prob, cov_prob, n_reads, nnz, (uint32_t)total_txps, device,
                               &opts, &s);
-    t_problem_size = 0;
     if (rc != OEM_OK) return rc;
     std::vector<uint32_t>().swap(vt);
     *used = true;

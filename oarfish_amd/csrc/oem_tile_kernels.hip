@@ -97,6 +97,11 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 #pragma unroll
         for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
     }
+    // the second element of the last pair of an odd-width slice belongs to the next row: it must
+    // carry no weight.  Done once here, so the passes below need no per-alignment select.
+    WT wz[kCh];
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) wz[k] = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : cur.w[k];
     if (ablate & 16) { // timing experiment: consume the operands, nothing else
         float acc = 0.f;
 #pragma unroll
@@ -109,8 +114,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 #pragma unroll
     for (int k = 0; k < kCh; ++k) {
         const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
-        const double wk = (uint32_t)k < width ? (double)cur.w[k] : 0.0;   // uniform select
-        x[k] = lds_ld(theta_l, off) * wk;                                  // em.rs:111
+        x[k] = lds_ld(theta_l, off) * (double)wz[k];                       // em.rs:111
         denom += x[k];
     }
     for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
@@ -221,23 +225,44 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     {
         uint32_t rt[kRem];
         WT rw[kRem];
+        if (td.remote_cnt && !(ablate & 1)) { // wave-uniform
+            // branch-free: out-of-range slots re-read the tile's last record and carry no weight,
+            // so the 4 x kRem loads issue back to back
+            const uint32_t last = td.remote_cnt - 1;
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) {
-            const uint32_t i = tx + k * kTileThreads;
-            rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0;
-            if (i < td.remote_cnt && !(ablate & 1)) {
-                const uint32_t o = td.remote_begin + i;
+            for (int k = 0; k < kRem; ++k) {
+                const uint32_t i = tx + k * kTileThreads;
+                const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
                 rt[k] = r_tid[o];
                 rw[k] = r_w[o];
                 rrow[k] = r_row[o];
                 rslot[k] = r_slot[o];
             }
+#pragma unroll
+            for (int k = 0; k < kRem; ++k)
+                if (tx + k * kTileThreads >= td.remote_cnt) rw[k] = (WT)0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kRem; ++k) { rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0; }
         }
 #pragma unroll
         for (int k = 0; k < kRem; ++k) rx[k] = theta[(ablate & 128) ? (rt[k] & 7u) : rt[k]] * (double)rw[k];
     }
     if (!(ablate & 32)) {
-        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) theta_l[i] = theta[td.lo + i];
+        {
+            constexpr uint32_t kPer = (kWin + kTileThreads - 1) / kTileThreads;
+            double tw[kPer];
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                const uint32_t i = tx + u * kTileThreads;
+                tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                const uint32_t i = tx + u * kTileThreads;
+                if (i < td.win_len) theta_l[i] = tw[u];
+            }
+        }
         for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
         for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     }
