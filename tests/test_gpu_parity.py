@@ -264,6 +264,52 @@ def test_aux_counts_and_assignment_probs(coverage):
     assert np.all(got[:2] == -1.0) and got[2] == 1.0
 
 
+def test_ragged_store_with_repeated_transcripts():
+    """Reads that hit the same transcript twice, empty reads, zero weights, a 100-alignment read."""
+    rng = np.random.default_rng(77)
+    T, R = 5000, 3000
+    lens = rng.integers(0, 9, size=R)
+    lens[5] = 100
+    rp = np.zeros(R + 1, dtype=np.uint64)
+    np.cumsum(lens, out=rp[1:])
+    nnz = int(rp[-1])
+    centre = np.repeat(rng.integers(0, T, size=R), lens)
+    tid = np.where(rng.random(nnz) < 0.8, (centre + rng.integers(-3, 4, size=nnz)) % T, rng.integers(0, T, size=nnz)).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 30, size=nnz).astype(np.float32) / np.float32(5)).astype(np.float32)
+    p[rng.random(nnz) < 0.05] = 0.0
+    o = c_oracle.Store(rp, tid, p, None, T)
+    want, wi = c_oracle.do_em(o, max_iter=300, conv_thresh=1e-3, min_iter_gate=1)
+    with DeviceStore(rp, tid, p, None, T) as d:
+        got, gi = d.em_run(None, 300, 1e-3, 1)
+        theta = rng.lognormal(0, 2, size=T)
+        assert_counts_close(d.m_step(theta), c_oracle.m_step(o, theta), R, T, 1e-10, "m_step")
+    assert abs(gi.niter - wi.niter) <= 1
+    assert_counts_close(got, want, R, T, RTOL if gi.niter != wi.niter else 1e-8, "ragged")
+
+
+def test_two_stores_from_two_threads():
+    """Calls on distinct handles are thread-safe (single_cell.rs:96-150 calls em::em from N workers)."""
+    import threading
+    stores = [synth.make_store(30_000, 2_000, seed=200 + i) for i in range(3)]
+    res = [None] * 3
+
+    def work(i):
+        st = stores[i]
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+            res[i] = [d.em_run(None, 150, 1e-3, 50)[0] for _ in range(3)]
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, st in enumerate(stores):
+        o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+        want, _ = c_oracle.do_em(o, max_iter=150, conv_thresh=1e-3)
+        for r in res[i]:
+            assert_counts_close(r, want, st.n_reads, st.n_txps, RTOL, f"thread {i}")
+
+
 def test_edge_cases():
     # empty store: every count 0
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:

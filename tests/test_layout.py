@@ -94,3 +94,42 @@ def test_layout_per_cell_problems(emul):
     o = c_oracle.Store(row_ptr, vtid, p, None, n_cells * T)
     got, stats = _run(emul, row_ptr, vtid, p, None, n_cells * T, theta, problem_size=T)
     np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-10, atol=1e-10)
+
+
+def test_layout_hypothesis_random_stores(emul):
+    """Property test: for arbitrary ragged stores -- empty reads, repeated
+    transcripts inside a read, zero weights, 1..3000 transcripts, far-apart targets -- the tiled layout
+    replayed on the host equals the oracle's m_step, with and without per-read multiplicities."""
+    from hypothesis import given, settings, strategies as st_, HealthCheck
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st_.integers(1, 3000), st_.integers(0, 400), st_.integers(0, 2**31 - 1), st_.booleans())
+    def run(T, R, seed, coverage):
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(0, 9, size=R)
+        if R and rng.random() < 0.3:
+            lens[rng.integers(0, R)] = 100                      # one --best-n sized read
+        rp = np.zeros(R + 1, dtype=np.uint64)
+        np.cumsum(lens, out=rp[1:])
+        nnz = int(rp[-1])
+        centre = rng.integers(0, T, size=R)
+        tid = np.empty(nnz, dtype=np.uint32)
+        for i in range(R):
+            s, e = int(rp[i]), int(rp[i + 1])
+            near = (centre[i] + rng.integers(-4, 5, size=e - s)) % T   # repeats inside a read are allowed
+            far = rng.integers(0, T, size=e - s)
+            tid[s:e] = np.where(rng.random(e - s) < 0.8, near, far)
+        p = np.exp(-rng.integers(0, 30, size=nnz).astype(np.float32) / np.float32(5)).astype(np.float32)
+        p[rng.random(nnz) < 0.05] = 0.0
+        cov = rng.uniform(0.0, 1.0, size=nnz) if coverage else None
+        theta = rng.lognormal(0, 2, size=T)
+        theta[rng.random(T) < 0.2] = 0.0
+        w = rng.integers(0, 4, size=R).astype(np.uint32)
+        o = c_oracle.Store(rp, tid, p, cov, T)
+        got, stats = _run(emul, rp, tid, p, cov, T, theta)
+        np.testing.assert_allclose(got, c_oracle.m_step(o, theta), rtol=1e-10, atol=1e-12)
+        got_w, _ = _run(emul, rp, tid, p, cov, T, theta, w)
+        np.testing.assert_allclose(got_w, c_oracle.m_step(o, theta, row_w=w), rtol=1e-10, atol=1e-12)
+        assert int(stats[1]) + int(stats[2]) == nnz and int(stats[3]) == int((lens > 0).sum())
+
+    run()
