@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Per-GPU compute time of one EM iteration for the row shard a rank would own at N = 1, 2, 4, 8
+(no collective: one GPU, the shard sizes only).  The driver's SCALE run adds the all-reduce."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oarfish_amd import synth
+from oarfish_amd.types import DeviceStore
+full = synth.make_store(10_000_000, 200_000, 8.0, threads=32)
+for n in (1, 2, 4, 8):
+    r1 = full.n_reads // n
+    a1 = int(full.row_ptr[r1])
+    d = DeviceStore(full.row_ptr[:r1 + 1], full.tid[:a1], full.as_prob[:a1], None, full.n_txps)
+    d.time_em_iters(20)
+    ms = d.time_em_iters(200) / 200
+    print(f"N={n}: shard {r1} reads, {a1} alignments: {ms*1e3:.1f} us per iteration (compute only) -> {1e3/ms:.0f} it/s upper bound")
+    d.close()
