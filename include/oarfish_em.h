@@ -113,6 +113,67 @@ int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uin
 int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass);
 
 /* --------------------------------------------------------------------- */
+/* store builder: the step right before the EM (host side, no GPU needed)  */
+/* --------------------------------------------------------------------- */
+
+/* AlignmentFilters (src/util/oarfish_types.rs:763-806), the fields filter() reads. */
+typedef struct {
+    uint32_t five_prime_clip;    /* :768 */
+    int64_t three_prime_clip;    /* :772 */
+    float score_threshold;       /* :778 */
+    float min_aligned_fraction;  /* :782 */
+    uint32_t min_aligned_len;    /* :786 */
+    int32_t which_strand;        /* :789  0 = Unknown (both), 1 = Forward only, 2 = Reverse only */
+    float score_prob_denom;      /* :804  D in exp((score - best) / D), default 5.0 */
+    uint32_t reserved;
+} oem_filters;
+
+/* One alignment record as AlnRecordLike exposes it (src/util/oarfish_types.rs:180-202, :264-326). */
+typedef struct {
+    uint32_t ref_id;     /* ref_id() */
+    uint32_t aln_start;  /* aln_start() */
+    uint32_t aln_end;    /* aln_end() */
+    uint32_t aln_span;   /* aln_span() */
+    int64_t score;       /* aln_score(); ignored unless OEM_REC_HAS_SCORE */
+    int64_t seq_len;     /* opt_sequence_len(); < 0 = None */
+    uint32_t flags;      /* OEM_REC_* */
+    uint32_t reserved;
+} oem_aln_record;
+#define OEM_REC_UNMAPPED 1u      /* is_unmapped() */
+#define OEM_REC_REVERSE 2u       /* is_reverse_complemented() */
+#define OEM_REC_SUPPLEMENTARY 4u /* is_supp() */
+#define OEM_REC_HAS_SCORE 8u     /* aln_score() is Some */
+
+/* DiscardTable (src/util/oarfish_types.rs:811-857). */
+typedef struct {
+    uint64_t discard_5p, discard_3p, discard_score, discard_aln_frac, discard_aln_len, discard_ori,
+        discard_supp, valid_best_aln, no_mapping, no_valid_aln;
+} oem_discard_table;
+
+typedef struct oem_builder oem_builder;
+
+/* InMemoryAlignmentStore::new + the transcript lengths filter() needs (TranscriptInfo.len). */
+int oem_builder_create(const oem_filters *filters, const uint64_t *txp_len, uint32_t n_txps,
+                       oem_builder **out);
+void oem_builder_destroy(oem_builder *b);
+/* InMemoryAlignmentStore::add_group (src/util/oarfish_types.rs:672-685): AlignmentFilters::filter
+ * (:955-1130: strand / supplementary / length / 3' / 5' filters, best-score tracking, aligned-
+ * fraction test, score threshold, as_prob = expf((score - best) / D) in f32, :1107-1113) followed by
+ * add_filtered_group (:718-738).  *out_kept = alignments appended (0: the read was dropped).
+ * The coverage intervals add_filtered_group also updates belong to the coverage model (not built). */
+int oem_builder_add_group(oem_builder *b, const oem_aln_record *records, uint32_t n_records,
+                          uint32_t *out_kept);
+int oem_builder_dims(const oem_builder *b, uint64_t *n_reads, uint64_t *nnz);
+int oem_builder_discard_table(const oem_builder *b, oem_discard_table *out);
+/* Copies the store out: row_ptr[n_reads+1], and per alignment tid / as_prob / start / end / strand
+ * (0 forward, 1 reverse); any output pointer may be NULL. */
+int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint32_t *tid, float *as_prob,
+                       uint32_t *start, uint32_t *end, uint8_t *strand);
+/* Uploads the built store (oem_store_create on the builder's arrays). */
+int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
+                             const oem_store_opts *opts, oem_store **out);
+
+/* --------------------------------------------------------------------- */
 /* EM                                                                     */
 /* --------------------------------------------------------------------- */
 

@@ -26,6 +26,8 @@ OEM_OPT_BATCH_BOOTSTRAP = 1
 ABI_SYMBOLS = [
     "oem_abi_version", "oem_last_error", "oem_device_count",
     "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_set_option",
+    "oem_builder_create", "oem_builder_destroy", "oem_builder_add_group", "oem_builder_dims",
+    "oem_builder_discard_table", "oem_builder_export", "oem_builder_store_create",
     "oem_m_step", "oem_em_run", "oem_aux_counts", "oem_assignment_probs",
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
@@ -48,6 +50,28 @@ class RunInfoC(C.Structure):
         ("reserved", C.c_uint32),
         ("rel_diff", C.c_double),
     ]
+
+
+class FiltersC(C.Structure):
+    _fields_ = [("five_prime_clip", C.c_uint32), ("three_prime_clip", C.c_int64),
+                ("score_threshold", C.c_float), ("min_aligned_fraction", C.c_float),
+                ("min_aligned_len", C.c_uint32), ("which_strand", C.c_int32),
+                ("score_prob_denom", C.c_float), ("reserved", C.c_uint32)]
+
+
+class AlnRecordC(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("aln_start", C.c_uint32), ("aln_end", C.c_uint32),
+                ("aln_span", C.c_uint32), ("score", C.c_int64), ("seq_len", C.c_int64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DiscardTableC(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("discard_5p", "discard_3p", "discard_score", "discard_aln_frac",
+                                          "discard_aln_len", "discard_ori", "discard_supp", "valid_best_aln",
+                                          "no_mapping", "no_valid_aln")]
+
+
+REC_UNMAPPED, REC_REVERSE, REC_SUPPLEMENTARY, REC_HAS_SCORE = 1, 2, 4, 8
 
 
 class StoreOptsC(C.Structure):
@@ -82,6 +106,14 @@ def lib() -> C.CDLL:
     L.oem_store_dims.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.oem_store_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.oem_store_set_option.argtypes = [vp, u32, u64]
+    L.oem_builder_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.oem_builder_destroy.argtypes = [vp]
+    L.oem_builder_destroy.restype = None
+    L.oem_builder_add_group.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.oem_builder_dims.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.oem_builder_discard_table.argtypes = [vp, vp]
+    L.oem_builder_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.oem_builder_store_create.argtypes = [vp, vp, i32, vp, C.POINTER(vp)]
     L.oem_m_step.argtypes = [vp, vp, vp, vp]
     L.oem_em_run.argtypes = [vp, vp, u32, f64, u32, vp, C.POINTER(RunInfoC)]
     L.oem_aux_counts.argtypes = [vp, vp, vp]

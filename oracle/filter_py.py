@@ -1,0 +1,112 @@
+"""Pure-Python restatement of AlignmentFilters::filter + add_filtered_group (TEST INFRASTRUCTURE ONLY).
+
+Reference: src/util/oarfish_types.rs:955-1130 (filter), :718-738 (add_filtered_group),
+:811-857 (DiscardTable).  Written independently of oarfish_amd/csrc/oem_builder.cpp, record by
+record with Python loops (small cases only); f32 arithmetic through numpy.float32 and the C
+library's expf (the function Rust's f32::exp lowers to on Linux).
+"""
+import ctypes
+import ctypes.util
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.expf.restype = ctypes.c_float
+_libm.expf.argtypes = [ctypes.c_float]
+f32 = np.float32
+I32_MIN = -2 ** 31
+
+
+@dataclass
+class Filters:
+    five_prime_clip: int = 2 ** 32 - 1
+    three_prime_clip: int = 2 ** 62
+    score_threshold: float = 0.95
+    min_aligned_fraction: float = 0.5
+    min_aligned_len: int = 50
+    which_strand: int = 0          # 0 unknown, 1 forward, 2 reverse
+    score_prob_denom: float = 5.0
+
+
+@dataclass
+class Rec:
+    ref_id: int
+    aln_start: int
+    aln_end: int
+    aln_span: int
+    score: object = None           # None = no AS tag
+    seq_len: object = None         # None = opt_sequence_len() is None
+    unmapped: bool = False
+    reverse: bool = False
+    supp: bool = False
+
+
+@dataclass
+class Store:
+    row_ptr: list = field(default_factory=lambda: [0])
+    tid: list = field(default_factory=list)
+    as_prob: list = field(default_factory=list)
+    start: list = field(default_factory=list)
+    end: list = field(default_factory=list)
+    strand: list = field(default_factory=list)
+    dt: dict = field(default_factory=lambda: dict(discard_5p=0, discard_3p=0, discard_score=0,
+                                                  discard_aln_frac=0, discard_aln_len=0, discard_ori=0,
+                                                  discard_supp=0, valid_best_aln=0, no_mapping=0,
+                                                  no_valid_aln=0))
+
+
+def add_group(st: Store, F: Filters, txp_len, ag):
+    if not ag:                                                      # :677
+        return 0
+    dt = st.dt
+    best, frac_best, len_best = I32_MIN, f32(0), 0                  # :963-969
+    n_mapped_in = sum(1 for x in ag if not x.unmapped)              # :974
+    seq_len = next((x.seq_len for x in ag if x.seq_len is not None), 0)  # :979-982
+    kept = []
+    for x in ag:                                                    # :985-1069
+        if x.unmapped:
+            continue
+        score = x.score if x.score is not None else I32_MIN
+        score = ((score + 2 ** 31) % 2 ** 32) - 2 ** 31              # `as i32`
+        if F.which_strand == 2 and not x.reverse:
+            dt["discard_ori"] += 1; continue
+        if F.which_strand == 1 and x.reverse:
+            dt["discard_ori"] += 1; continue
+        if x.supp:
+            dt["discard_supp"] += 1; continue
+        if x.aln_span < F.min_aligned_len:
+            dt["discard_aln_len"] += 1; continue
+        if x.aln_end <= txp_len[x.ref_id] - F.three_prime_clip:
+            dt["discard_3p"] += 1; continue
+        if x.aln_start >= F.five_prime_clip:
+            dt["discard_5p"] += 1; continue
+        if score > best:
+            best, len_best = score, x.aln_span
+            frac_best = f32(x.aln_span) / f32(seq_len) if seq_len > 0 else f32(0)
+        kept.append(x)
+    if not kept or len_best == 0 or best <= 0:                      # :1071-1083
+        dt["no_mapping" if n_mapped_in == 0 else "no_valid_aln"] += 1
+        return 0
+    if frac_best < f32(F.min_aligned_fraction):                     # :1084-1089
+        dt["discard_aln_frac"] += 1
+        return 0
+    dt["valid_best_aln"] += 1
+    mscore = f32(best)
+    inv_max = f32(1.0) / mscore
+    n = 0
+    for x in kept:                                                  # :1107-1118
+        sc = x.score if x.score is not None else 0
+        sc = ((sc + 2 ** 31) % 2 ** 32) - 2 ** 31
+        fscore = f32(sc)
+        if not (fscore * inv_max >= f32(F.score_threshold)):
+            dt["discard_score"] += 1
+            continue
+        fexp = (fscore - mscore) / f32(F.score_prob_denom)
+        st.as_prob.append(f32(_libm.expf(ctypes.c_float(float(fexp)))))
+        st.tid.append(x.ref_id); st.start.append(x.aln_start); st.end.append(x.aln_end)
+        st.strand.append(1 if x.reverse else 0)
+        n += 1
+    if n:
+        st.row_ptr.append(len(st.tid))                              # :733
+    return n

@@ -1,0 +1,130 @@
+"""The store builder: AlignmentFilters::filter + add_filtered_group
+(src/util/oarfish_types.rs:955-1130, :718-738) as oem_builder_* in the C ABI, against a pure-Python
+restatement.  Integer work and f32 probabilities: bit-exact.  Host-only; the last test uploads the
+built store and checks the EM on it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oarfish_amd import _lib
+from oracle import filter_py as fp
+
+
+def _builder(F: fp.Filters, txp_len):
+    L = _lib.lib()
+    fc = _lib.FiltersC(F.five_prime_clip, F.three_prime_clip, F.score_threshold, F.min_aligned_fraction,
+                       F.min_aligned_len, F.which_strand, F.score_prob_denom, 0)
+    tl = np.ascontiguousarray(txp_len, dtype=np.uint64)
+    h = C.c_void_p()
+    _lib.check(L.oem_builder_create(C.addressof(fc), tl.ctypes.data, len(tl), C.byref(h)))
+    return h
+
+
+def _add(h, group):
+    L = _lib.lib()
+    arr = (_lib.AlnRecordC * max(len(group), 1))()
+    for i, x in enumerate(group):
+        flags = (_lib.REC_UNMAPPED if x.unmapped else 0) | (_lib.REC_REVERSE if x.reverse else 0) | \
+                (_lib.REC_SUPPLEMENTARY if x.supp else 0) | (_lib.REC_HAS_SCORE if x.score is not None else 0)
+        arr[i] = _lib.AlnRecordC(x.ref_id, x.aln_start, x.aln_end, x.aln_span, x.score if x.score is not None else 0,
+                                 x.seq_len if x.seq_len is not None else -1, flags, 0)
+    kept = C.c_uint32(0)
+    _lib.check(L.oem_builder_add_group(h, C.addressof(arr), len(group), C.byref(kept)))
+    return kept.value
+
+
+def _export(h):
+    L = _lib.lib()
+    R, nnz = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(L.oem_builder_dims(h, C.byref(R), C.byref(nnz)))
+    rp = np.zeros(R.value + 1, dtype=np.uint64)
+    tid = np.zeros(nnz.value, dtype=np.uint32)
+    p = np.zeros(nnz.value, dtype=np.float32)
+    s = np.zeros(nnz.value, dtype=np.uint32)
+    e = np.zeros(nnz.value, dtype=np.uint32)
+    sd = np.zeros(nnz.value, dtype=np.uint8)
+    _lib.check(L.oem_builder_export(h, rp.ctypes.data, tid.ctypes.data, p.ctypes.data, s.ctypes.data,
+                                    e.ctypes.data, sd.ctypes.data))
+    dt = _lib.DiscardTableC()
+    _lib.check(L.oem_builder_discard_table(h, C.addressof(dt)))
+    return rp, tid, p, s, e, sd, {n: getattr(dt, n) for n, _ in _lib.DiscardTableC._fields_}
+
+
+def test_hand_checked_read():
+    """Best score 1000, D = 5, threshold 0.95: scores 1000 / 990 / 960 / 940 -> p = 1, e^-2, e^-8, dropped."""
+    F = fp.Filters()
+    h = _builder(F, [2000] * 4)
+    g = [fp.Rec(0, 10, 1500, 1400, 1000, 1500), fp.Rec(1, 10, 1500, 1400, 990), fp.Rec(2, 5, 1400, 1400, 960),
+         fp.Rec(3, 5, 1400, 1400, 940)]
+    assert _add(h, g) == 3
+    rp, tid, p, s, e, sd, dt = _export(h)
+    assert list(rp) == [0, 3] and list(tid) == [0, 1, 2]
+    np.testing.assert_allclose(p, [1.0, np.exp(-2.0), np.exp(-8.0)], rtol=3e-7)
+    assert dt["discard_score"] == 1 and dt["valid_best_aln"] == 1
+    # a read whose best alignment covers too little of it is dropped whole (:1084-1089)
+    assert _add(h, [fp.Rec(0, 10, 900, 300, 500, 1500)]) == 0
+    # unmapped only -> no_mapping; mapped but non-positive best score -> no_valid_aln
+    assert _add(h, [fp.Rec(0, 0, 0, 0, None, 100, unmapped=True)]) == 0
+    assert _add(h, [fp.Rec(0, 10, 900, 800, 0, 900)]) == 0
+    rp, tid, p, s, e, sd, dt = _export(h)
+    assert list(rp) == [0, 3] and dt["discard_aln_frac"] == 1 and dt["no_mapping"] == 1 and dt["no_valid_aln"] == 1
+    _lib.lib().oem_builder_destroy(h)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_builder_matches_python_restatement(seed):
+    rng = np.random.default_rng(seed)
+    T = 50
+    txp_len = rng.integers(300, 4000, size=T)
+    F = fp.Filters(five_prime_clip=int(rng.choice([2 ** 32 - 1, 400])), three_prime_clip=int(rng.choice([2 ** 62, 600])),
+                   score_threshold=float(rng.choice([0.95, 0.9])), min_aligned_fraction=float(rng.choice([0.5, 0.7])),
+                   min_aligned_len=int(rng.choice([50, 200])), which_strand=int(rng.integers(0, 3)),
+                   score_prob_denom=float(rng.choice([5.0, 2.5])))
+    h = _builder(F, txp_len)
+    ref = fp.Store()
+    for _ in range(800):
+        n = int(rng.integers(0, 7))
+        read_len = int(rng.integers(200, 3000))
+        best = int(rng.integers(-5, 3000))
+        g = []
+        for j in range(n):
+            t = int(rng.integers(0, T))
+            span = int(rng.integers(20, read_len + 1))
+            start = int(rng.integers(0, max(1, int(txp_len[t]) - 10)))
+            sc = None if rng.random() < 0.03 else int(best - rng.integers(0, max(1, abs(best) // 8 + 2)))
+            g.append(fp.Rec(t, start, start + span, span, sc, read_len if (j == 0 or rng.random() < 0.5) else None,
+                            unmapped=rng.random() < 0.05, reverse=rng.random() < 0.3, supp=rng.random() < 0.05))
+        assert _add(h, g) == fp.add_group(ref, F, txp_len, g)
+    rp, tid, p, s, e, sd, dt = _export(h)
+    assert list(rp) == ref.row_ptr and list(tid) == ref.tid and list(s) == ref.start and list(e) == ref.end
+    assert list(sd) == ref.strand and dt == ref.dt
+    assert np.array_equal(p.view(np.uint32), np.asarray(ref.as_prob, dtype=np.float32).view(np.uint32))  # bit-exact f32
+    assert len(rp) - 1 > 20 and dt["discard_score"] + dt["discard_3p"] + dt["discard_5p"] > 0 and dt["no_valid_aln"] > 0
+    _lib.lib().oem_builder_destroy(h)
+
+
+@pytest.mark.gpu
+def test_built_store_runs_the_em():
+    from oracle import c_oracle
+    rng = np.random.default_rng(9)
+    T = 300
+    txp_len = rng.integers(800, 4000, size=T)
+    F = fp.Filters()
+    h = _builder(F, txp_len)
+    for _ in range(5000):
+        t0 = int(rng.integers(0, T))
+        read_len = 1000
+        g = [fp.Rec(int((t0 + j) % T), 5, 905, 900, 1800 - int(rng.integers(0, 60)) * (j > 0), read_len) for j in range(int(rng.integers(1, 5)))]
+        _add(h, g)
+    rp, tid, p, *_ = _export(h)
+    hs = C.c_void_p()
+    _lib.check(_lib.lib().oem_builder_store_create(h, None, 0, None, C.byref(hs)))
+    out = np.zeros(T)
+    ri = _lib.RunInfoC()
+    _lib.check(_lib.lib().oem_em_run(hs, None, 200, 1e-3, 50, out.ctypes.data, C.byref(ri)))
+    _lib.lib().oem_store_destroy(hs)
+    _lib.lib().oem_builder_destroy(h)
+    want, wi = c_oracle.do_em(c_oracle.Store(rp, tid, p, None, T), max_iter=200, conv_thresh=1e-3)
+    assert abs(ri.niter - wi.niter) <= 1
+    np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)
