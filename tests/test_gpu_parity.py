@@ -310,6 +310,37 @@ def test_two_stores_from_two_threads():
             assert_counts_close(r, want, st.n_reads, st.n_txps, RTOL, f"thread {i}")
 
 
+def test_row_shard_semantics_single_rank():
+    """What a rank does with its shard, checked on one GPU with a 1-rank communicator: the uniform
+    init uses the GLOBAL read count (em.rs:154,165), and the shard's bootstrap multiplicities are the
+    slice of the global resample it owns (same counter-based stream on every rank)."""
+    from oarfish_amd import dist as odist
+    st = synth.make_store(80_000, 5_000, seed=300)
+    world = 3
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as full:
+        w_full = full.bootstrap_weights(42, 1)
+        partial_sum = np.zeros(st.n_txps)
+        theta0 = np.full(st.n_txps, st.n_reads / st.n_txps)
+        want_step = full.m_step(theta0)
+    comm = odist.create_comm(0, 1, 0)
+    try:
+        for rank in range(world):
+            sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, rank, world)
+            with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps) as d:
+                d.attach_comm(comm.handle, st.n_reads, sh.row_begin)
+                w = d.bootstrap_weights(42, 1)
+                assert np.array_equal(w, w_full[sh.row_begin:sh.row_end])
+                partial_sum += d.m_step(theta0)                  # rank-local partial counts
+                # one iteration from the uniform init = one pass from theta = R_global / T
+                one, info = d.em_run(None, 1, 0.0, 50)
+                o = c_oracle.Store(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps)
+                ref, _ = c_oracle.do_em(o, init=theta0, max_iter=1, conv_thresh=0.0)
+                assert_counts_close(one, ref, st.n_reads, st.n_txps, 1e-9, f"shard {rank}")
+        assert_counts_close(partial_sum, want_step, st.n_reads, st.n_txps, 1e-10, "sum of shard partials")
+    finally:
+        comm.close()
+
+
 def test_edge_cases():
     # empty store: every count 0
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:
