@@ -21,14 +21,6 @@ namespace oem {
 // ---------------------------------------------------------------------------
 static thread_local char t_err[512] = "";
 
-void set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(t_err, sizeof(t_err), fmt, ap);
-    va_end(ap);
-}
-
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;

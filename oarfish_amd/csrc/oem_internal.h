@@ -16,7 +16,6 @@ namespace oem {
 // ---------------------------------------------------------------------------
 // error plumbing: every ABI entry point funnels through these
 // ---------------------------------------------------------------------------
-void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
 
 #define OEM_HIP(expr)                                                                      \
