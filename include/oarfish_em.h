@@ -169,6 +169,18 @@ int oem_builder_discard_table(const oem_builder *b, oem_discard_table *out);
  * (0 forward, 1 reverse); any output pointer may be NULL. */
 int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint32_t *tid, float *as_prob,
                        uint32_t *start, uint32_t *end, uint8_t *strand);
+/* The bulk coverage model: per-transcript binned coverage of the
+ * retained alignments (TranscriptInfo::with_len_and_bin_width + add_interval,
+ * src/util/oarfish_types.rs:460-468, :496-538), the clamped logistic bin probabilities
+ * (logistic_prob, src/util/logistic_probability.rs:7-79; min coverage total_weight/100, f32 bin
+ * counts) and the per-alignment coverage probability normalised to sum 1 per read
+ * (normalize_read_probs, src/util/normalize_probability.rs:5-74).  out_cov_prob: nnz f64 in the
+ * builder's alignment order -- the `cov_prob` column of oem_store_create.  bin_width: --bin-width
+ * (prog_opts.rs:555, default 100); growth_rate: --growth-rate (prog_opts.rs:502, default 2.0).
+ * Where the reference would panic (degenerate bins, non-finite probability) this returns
+ * OEM_ERR_STATE. */
+int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width, double growth_rate,
+                               double *out_cov_prob);
 /* Uploads the built store (oem_store_create on the builder's arrays). */
 int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
                              const oem_store_opts *opts, oem_store **out);

@@ -7,6 +7,7 @@
 // append them to the CSR the EM consumes.  This runs once per store on the host; nothing here
 // touches the GPU.  BAM parsing stays out of scope: the caller supplies the record fields the
 // AlnRecordLike trait exposes (:180-202).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -141,6 +142,111 @@ extern "C" int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint3
     if (start && nnz) std::memcpy(start, b->start.data(), sizeof(uint32_t) * nnz);
     if (end && nnz) std::memcpy(end, b->end.data(), sizeof(uint32_t) * nnz);
     if (strand && nnz) std::memcpy(strand, b->strand.data(), nnz);
+    return OEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// coverage model (bulk): oarfish_types.rs:460-538, logistic_probability.rs:7-79,
+// normalize_probability.rs:5-74
+// ---------------------------------------------------------------------------
+extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width_u, double growth_rate,
+                                          double *out)
+{
+    if (!b || (!out && !b->tid.empty())) return fail(OEM_ERR_ARG, "oem_builder_coverage_probs: NULL argument");
+    if (bin_width_u == 0) return fail(OEM_ERR_ARG, "coverage model with 0 bin width is not implemented (logistic_probability.rs:59)");
+    const size_t T = b->txp_len.size(), nnz = b->tid.size();
+    struct Txp { std::vector<double> bins, prob; double total_weight = 0.0, lenf = 0.0; };
+    std::vector<Txp> txps(T);
+    for (size_t t = 0; t < T; ++t) {                                   // with_len_and_bin_width (:460-468)
+        txps[t].lenf = (double)b->txp_len[t];
+        txps[t].bins.assign((size_t)std::ceil((double)b->txp_len[t] / (double)bin_width_u), 0.0);
+    }
+    // add_interval for every retained alignment, in store order (add_filtered_group, :725-728)
+    for (size_t j = 0; j < nnz; ++j) {
+        Txp &tx = txps[b->tid[j]];
+        const size_t num_intervals = tx.bins.size();
+        const double nf = (double)num_intervals, tlen_f = tx.lenf;
+        const double bw = std::round(tlen_f / nf);                     // :501
+        uint32_t start = b->start[j], stop = b->end[j];
+        start = std::min(start, stop);                                 // :502
+        stop = std::max(start, stop);                                  // :503
+        const size_t start_bin = (size_t)std::floor(((double)start / tlen_f) * nf); // :504
+        const size_t end_bin = (size_t)std::floor(((double)stop / tlen_f) * nf);    // :505
+        if (start_bin > end_bin || end_bin > num_intervals)
+            return fail(OEM_ERR_STATE, "add_interval: alignment [%u,%u) outside transcript %u of length %llu", start,
+                        stop, b->tid[j], (unsigned long long)b->txp_len[b->tid[j]]);
+        for (size_t bi = start_bin; bi < end_bin; ++bi) {              // :515-536 (end_bin itself is not visited)
+            const double bidxf = (double)bi;
+            const uint32_t cbs = (uint32_t)(bidxf * bw);
+            const uint32_t cbe = (uint32_t)std::min((bidxf + 1.0) * bw, tlen_f);
+            const uint32_t olap = start <= cbe ? std::min(stop, cbe) - std::max(start, cbs) : 0u; // :507-513 (u32)
+            const double olfrac = (double)olap / (double)(uint32_t)(cbe - cbs);
+            tx.bins[bi] += olfrac;
+            if (olfrac > 1.0 + 2.220446049250313e-16)                  // :524-535: the reference panics here
+                return fail(OEM_ERR_STATE, "coverage computation error at transcript %u bin %zu", b->tid[j], bi);
+        }
+        tx.total_weight += 1.0;                                        // :537 (weight 1.0, :727)
+    }
+    // logistic_prob (logistic_probability.rs:41-79)
+    for (size_t t = 0; t < T; ++t) {
+        Txp &tx = txps[t];
+        const size_t n = tx.bins.size();
+        if (n == 0) return fail(OEM_ERR_STATE, "transcript %zu has no coverage bins", t); // assert (:54)
+        const double min_cov = tx.total_weight / 100.;                 // :55
+        for (double &e : tx.bins) e += min_cov;                        // :56
+        // get_normalized_counts_and_lengths (oarfish_types.rs:471-493): f32 counts; the bin-width
+        // assertion is reproduced because the reference would panic there
+        const float bwf = (float)std::round(tx.lenf / (double)n);
+        for (size_t bi = 0; bi < n; ++bi) {
+            const float bs = (float)bi * bwf, be = std::min(((float)bi + 1.0f) * bwf, (float)tx.lenf);
+            if (!(be > bs)) return fail(OEM_ERR_STATE, "transcript %zu: degenerate coverage bin %zu (assert, oarfish_types.rs:490)", t, bi);
+        }
+        double count_sum = 0.0;                                        // logstic_function (:13-39)
+        for (double e : tx.bins) count_sum += (double)(float)e;
+        tx.prob.assign(n, 0.0);
+        if (count_sum <= 1e-8) continue;                               // :21-23
+        const double expected = count_sum / (double)n;                 // :27
+        for (size_t bi = 0; bi < n; ++bi) {
+            const double diff = (expected - (double)(float)tx.bins[bi]) / expected;       // :32
+            double r = 1.0 / (1.0 + std::exp(-growth_rate * diff));    // logistic (:7-10)
+            r = r < 1e-8 ? 1e-8 : (r > 0.99999 ? 0.99999 : r);
+            tx.prob[bi] = r;
+        }
+    }
+    // normalize_read_probs (normalize_probability.rs:5-74)
+    const double bin_length = (double)bin_width_u;
+    const size_t R = b->row_ptr.size() - 1;
+    for (size_t r = 0; r < R; ++r) {
+        double nprob_sum = 0.0;
+        for (uint64_t j = b->row_ptr[r]; j < b->row_ptr[r + 1]; ++j) {
+            const Txp &tx = txps[b->tid[j]];
+            const double start_aln = (double)b->start[j], end_aln = (double)b->end[j], tlen = (double)b->txp_len[b->tid[j]];
+            const size_t start_bin = (size_t)(start_aln / bin_length);                     // :25
+            const size_t end_bin = std::min((size_t)(end_aln / bin_length), tx.prob.size() - 1); // :26-27
+            double total_weight = 0.0, cov_prob = 0.0;
+            if (start_bin == end_bin) {                                // :33-35
+                const double w = (end_aln - start_aln) / bin_length;
+                total_weight = w;
+                cov_prob = w * tx.prob[start_bin];
+            } else {
+                for (size_t i = start_bin; i < end_bin; ++i) {         // :37-46 (end_bin itself is not visited)
+                    const double w = i == start_bin
+                                         ? (std::min(bin_length * (double)i + bin_length, tlen) - start_aln) / bin_length
+                                         : 1.0;
+                    total_weight += w;
+                    cov_prob += w * tx.prob[i];
+                }
+            }
+            const double expected = cov_prob / total_weight;           // :58
+            if (std::isnan(cov_prob) || std::isinf(cov_prob) || std::isnan(expected)) // :49-57 (+ the 0/0 of an empty bin range)
+                return fail(OEM_ERR_STATE, "normalize_read_probs: invalid coverage probability for alignment %llu",
+                            (unsigned long long)j);
+            out[j] = expected;
+            nprob_sum += expected;
+        }
+        const double denom = nprob_sum > 0.0 ? nprob_sum : 1.0;        // :62
+        for (uint64_t j = b->row_ptr[r]; j < b->row_ptr[r + 1]; ++j) out[j] /= denom; // :65-69
+    }
     return OEM_OK;
 }
 

@@ -110,3 +110,79 @@ def add_group(st: Store, F: Filters, txp_len, ag):
     if n:
         st.row_ptr.append(len(st.tid))                              # :733
     return n
+
+
+# ---------------------------------------------------------------------------------------------
+# Coverage model (bulk), restated independently of oem_builder.cpp:
+#   TranscriptInfo::with_len_and_bin_width / add_interval   oarfish_types.rs:460-468, :496-538
+#   logistic_prob / logstic_function / logistic             logistic_probability.rs:7-79
+#   get_normalized_counts_and_lengths                       oarfish_types.rs:471-493
+#   normalize_read_probs                                    normalize_probability.rs:5-74
+# ---------------------------------------------------------------------------------------------
+import math
+
+
+def _rust_round(x):  # f64::round: half away from zero
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
+def coverage_probs(st: Store, txp_len, bin_width: int, growth_rate: float):
+    T = len(txp_len)
+    bins = [[0.0] * int(math.ceil(float(txp_len[t]) / float(bin_width))) for t in range(T)]
+    total_weight = [0.0] * T
+    U32 = 2 ** 32
+    for j, t in enumerate(st.tid):                               # add_interval (:496-538)
+        n = len(bins[t]); nf = float(n); tlen_f = float(txp_len[t])
+        bw = _rust_round(tlen_f / nf)
+        start, stop = st.start[j], st.end[j]
+        start = min(start, stop)
+        stop = max(start, stop)
+        sb = int(math.floor((float(start) / tlen_f) * nf))
+        eb = int(math.floor((float(stop) / tlen_f) * nf))
+        for bi in range(sb, eb):
+            cbs = int(float(bi) * bw) % U32
+            cbe = int(min((float(bi) + 1.0) * bw, tlen_f)) % U32
+            olap = ((min(stop, cbe) - max(start, cbs)) % U32) if start <= cbe else 0
+            bins[t][bi] += float(olap) / float((cbe - cbs) % U32)
+        total_weight[t] += 1.0
+    prob = []
+    for t in range(T):                                           # logistic_prob (:41-79)
+        min_cov = total_weight[t] / 100.0
+        b = [e + min_cov for e in bins[t]]
+        counts = [float(np.float32(e)) for e in b]               # f32 counts (oarfish_types.rs:478)
+        csum = 0.0
+        for c in counts:
+            csum += c
+        if csum <= 1e-8:
+            prob.append([0.0] * len(b)); continue
+        expected = csum / len(b)
+        pr = []
+        for c in counts:
+            diff = (expected - c) / expected
+            r = 1.0 / (1.0 + math.exp(-growth_rate * diff))
+            pr.append(min(max(r, 1e-8), 0.99999))
+        prob.append(pr)
+    out = [0.0] * len(st.tid)
+    bl = float(bin_width)
+    for r in range(len(st.row_ptr) - 1):                         # normalize_read_probs (:5-74)
+        s = 0.0
+        for j in range(st.row_ptr[r], st.row_ptr[r + 1]):
+            t = st.tid[j]
+            sa, ea, tlen = float(st.start[j]), float(st.end[j]), float(txp_len[t])
+            sb = int(sa / bl)
+            eb = min(int(ea / bl), len(prob[t]) - 1)
+            if sb == eb:
+                w = (ea - sa) / bl
+                tw, cp = w, w * prob[t][sb]
+            else:
+                tw, cp = 0.0, 0.0
+                for i in range(sb, eb):
+                    w = (min(bl * float(i) + bl, tlen) - sa) / bl if i == sb else 1.0
+                    tw += w
+                    cp += w * prob[t][i]
+            out[j] = cp / tw
+            s += out[j]
+        d = s if s > 0 else 1.0
+        for j in range(st.row_ptr[r], st.row_ptr[r + 1]):
+            out[j] /= d
+    return out

@@ -128,3 +128,75 @@ def test_built_store_runs_the_em():
     want, wi = c_oracle.do_em(c_oracle.Store(rp, tid, p, None, T), max_iter=200, conv_thresh=1e-3)
     assert abs(ri.niter - wi.niter) <= 1
     np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed,bin_width,growth", [(5, 100, 2.0), (6, 50, 1.0), (7, 200, 3.5)])
+def test_coverage_model_matches_python_restatement(seed, bin_width, growth):
+    """add_interval binning + logistic bin probabilities + per-read
+    normalisation (oarfish_types.rs:496-538, logistic_probability.rs, normalize_probability.rs).
+    f64 with the same operation order and the C library's exp: equal to 1e-15."""
+    rng = np.random.default_rng(seed)
+    T = 40
+    txp_len = rng.integers(600, 5000, size=T)
+    F = fp.Filters()
+    h = _builder(F, txp_len)
+    ref = fp.Store()
+    for _ in range(1500):
+        t0 = int(rng.integers(0, T))
+        g = []
+        for j in range(int(rng.integers(1, 5))):
+            t = int((t0 + j) % T)
+            L = int(txp_len[t])
+            start = int(rng.integers(0, max(1, L - 120)))
+            end = int(rng.integers(start + 100, L + 1)) if start + 100 <= L else L
+            span = end - start
+            g.append(fp.Rec(t, start, end, span, 2000 - int(rng.integers(0, 40)) * (j > 0), 1000 if span >= 600 else max(span, 1)))
+        assert _add(h, g) == fp.add_group(ref, F, txp_len, g)
+    rp, tid, p, s, e, sd, dt = _export(h)
+    assert len(tid) > 1000
+    cov = np.zeros(len(tid), dtype=np.float64)
+    _lib.check(_lib.lib().oem_builder_coverage_probs(h, bin_width, growth, cov.ctypes.data))
+    want = np.asarray(fp.coverage_probs(ref, txp_len, bin_width, growth))
+    np.testing.assert_allclose(cov, want, rtol=1e-15, atol=0)
+    sums = np.add.reduceat(cov, rp[:-1].astype(np.int64))
+    np.testing.assert_allclose(sums, 1.0, rtol=1e-12)            # normalised per read
+    assert cov.min() > 0 and len(np.unique(np.round(cov, 6))) > 50
+    # bin width 0 is rejected as in the reference (unimplemented!)
+    assert _lib.lib().oem_builder_coverage_probs(h, 0, growth, cov.ctypes.data) == _lib.OEM_ERR_ARG
+    _lib.lib().oem_builder_destroy(h)
+
+
+@pytest.mark.gpu
+def test_records_to_abundances_with_coverage_model():
+    """End to end on the device: alignment records -> filters -> as_prob, coverage model -> cov_prob,
+    upload, EM (the --model-coverage flow of bulk.rs:103-108,131-159)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(15)
+    T = 120
+    txp_len = rng.integers(900, 4000, size=T)
+    F = fp.Filters()
+    h = _builder(F, txp_len)
+    for _ in range(8000):
+        t0 = int(rng.integers(0, T))
+        g = []
+        for j in range(int(rng.integers(1, 4))):
+            t = int((t0 + j) % T)
+            L = int(txp_len[t])
+            start = int(rng.integers(0, 60))
+            end = int(rng.integers(L - 60, L + 1))
+            g.append(fp.Rec(t, start, end, end - start, 1500 - int(rng.integers(0, 50)) * (j > 0), end - start))
+        _add(h, g)
+    rp, tid, p, *_ = _export(h)
+    cov = np.zeros(len(tid))
+    _lib.check(_lib.lib().oem_builder_coverage_probs(h, 100, 2.0, cov.ctypes.data))
+    hs = C.c_void_p()
+    _lib.check(_lib.lib().oem_builder_store_create(h, cov.ctypes.data, 0, None, C.byref(hs)))
+    out = np.zeros(T)
+    ri = _lib.RunInfoC()
+    _lib.check(_lib.lib().oem_em_run(hs, None, 1000, 1e-3, 1, out.ctypes.data, C.byref(ri)))
+    _lib.lib().oem_store_destroy(hs)
+    _lib.lib().oem_builder_destroy(h)
+    want, wi = c_oracle.do_em(c_oracle.Store(rp, tid, p, cov, T), max_iter=1000, conv_thresh=1e-3, min_iter_gate=1)
+    assert abs(ri.niter - wi.niter) <= 1
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-6)
+    assert abs(out.sum() - (len(rp) - 1)) < 1e-6 * len(rp)
