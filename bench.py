@@ -193,6 +193,16 @@ def main():
                     kernel="k_em_tile + k_remote_fold (one E/M pass)", kernel_avg_ms=k_ms,
                     algorithmic_bytes_per_launch=alg_bytes, traffic_source=traffic_src)
 
+    # EM to convergence with the reference's defaults (max_iter 1000, thresh 1e-3), both gates
+    sync()
+    conv = {}
+    for gate, name in ((1, "em_par"), (50, "em")):
+        tc = time.perf_counter()
+        _cnt, info = store.em_run(None, 1000, 1e-3, gate)
+        sync()
+        conv[name] = dict(niter=info.niter, n_passes=info.n_passes, converged=info.converged,
+                          seconds=time.perf_counter() - tc)
+
     # bootstraps/sec (each = one resampled EM to convergence, em.rs:273-290)
     boots = None
     if args.bootstraps > 0:
@@ -231,6 +241,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "bootstraps": boots,
+            "em_to_convergence": conv,
         }
         print(json.dumps(out))
     store.close()
