@@ -34,6 +34,13 @@ struct SliceRegsB {
     uint32_t c[kBCh / 2];
 };
 
+template <bool kNT, typename T>
+__device__ __forceinline__ T ld_stream_b(const T *p)
+{
+    return kNT ? __builtin_nontemporal_load(p) : *p; // see ld_stream in oem_tile_kernels.hip
+}
+
+template <bool kNT>
 __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restrict__ wbase,
                                              const uint32_t *__restrict__ cbase, uint32_t lane,
                                              uint32_t width)
@@ -41,9 +48,9 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restr
 #pragma unroll
     for (int g = 0; g < kBCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            r.w[2 * g] = wbase[(2 * g) * 64 + lane];
-            r.w[2 * g + 1] = wbase[(2 * g + 1) * 64 + lane];
-            r.c[g] = cbase[g * 64 + lane];
+            r.w[2 * g] = ld_stream_b<kNT>(&wbase[(2 * g) * 64 + lane]);
+            r.w[2 * g + 1] = ld_stream_b<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            r.c[g] = ld_stream_b<kNT>(&cbase[g * 64 + lane]);
         } else {
             r.w[2 * g] = 0.f;
             r.w[2 * g + 1] = 0.f;
@@ -56,7 +63,7 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restr
 // lane, slices prefetched one ahead, operands landed with one counted wait, count window in
 // kCopies interleaved copies -- with every LDS / queue / theta entity carrying kB replicates.
 // Window entry (c, b, copy p) lives at ((c * kB + b) * kCopies + p).
-template <int kThreads, int kRem, int kCopies, int kMinWaves>
+template <int kThreads, int kRem, int kCopies, int kMinWaves, bool kNT>
 __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const float *__restrict__ w, const uint32_t *__restrict__ r_tid, const float *__restrict__ r_w,
@@ -118,10 +125,10 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
             rt[k] = 0; rw[k] = 0.f; rrow[k] = 0; rslot[k] = 0;
             if (i < td.remote_cnt) {
                 const uint32_t o = td.remote_begin + i;
-                rt[k] = r_tid[o];
-                rw[k] = r_w[o];
-                rrow[k] = r_row[o];
-                rslot[k] = r_slot[o];
+                rt[k] = ld_stream_b<kNT>(&r_tid[o]);
+                rw[k] = ld_stream_b<kNT>(&r_w[o]);
+                rrow[k] = ld_stream_b<kNT>(&r_row[o]);
+                rslot[k] = ld_stream_b<kNT>(&r_slot[o]);
             }
         }
 #pragma unroll
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
     }
     constexpr uint32_t kSets = kPerWave > 1 ? 2 : 1;
     SliceRegsB R[kSets];
-    load_slice_b(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+    load_slice_b<kNT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
 
     for (uint32_t i = tx; i < td.win_len * kB; i += kThreads) theta_l[i] = th(theta[(size_t)td.lo * kB + i], i % kB);
     for (uint32_t i = tx; i < td.win_len * kB * kCopies; i += kThreads) cnt_l[i] = 0.0;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
     for (uint32_t q = 0; q < kPerWave; ++q) {
         const uint32_t s = wave + kWaves * q;
         if (q + 1 < kPerWave)
-            load_slice_b(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+            load_slice_b<kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                          wid[q + 1]);
         if (s >= td.n_slices) continue;
         const SliceRegsB &cur = R[q % kSets];
@@ -432,10 +439,17 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         const char *e = getenv("OEM_BATCH_VARIANT"); // tuning knob
         return e ? atoi(e) : 0;
     }();
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * 6 + t.n_remote * 14;
+    const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
+#define OEM_TILE_B_NT(TH, REM, NC, MW, NT)                                                                \
+    hipLaunchKernelGGL((k_em_tile_b<TH, REM, NC, MW, NT>), dim3(t.n_tiles), dim3(TH), 0, s->stream,         \
+                       t.tiles, t.codes, (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row,    \
+                       t.r_slot, bb.queue, t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
 #define OEM_TILE_B(TH, REM, NC, MW)                                                                       \
-    hipLaunchKernelGGL((k_em_tile_b<TH, REM, NC, MW>), dim3(t.n_tiles), dim3(TH), 0, s->stream, t.tiles,    \
-                       t.codes, (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot,   \
-                       bb.queue, t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
+    do {                                                                                                  \
+        if (nt) OEM_TILE_B_NT(TH, REM, NC, MW, true);                                                     \
+        else OEM_TILE_B_NT(TH, REM, NC, MW, false);                                                       \
+    } while (0)
     switch (variant) {
     case 1: OEM_TILE_B(256, 6, 4, 2); break;
     case 2: OEM_TILE_B(512, 3, 2, 2); break;
@@ -444,6 +458,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     default: OEM_TILE_B(256, 6, 2, 2); break;
     }
 #undef OEM_TILE_B
+#undef OEM_TILE_B_NT
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);

@@ -34,6 +34,18 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// The matrix streams (weights, codes, remote records) are touched once per pass; theta and the
+// tile descriptors are re-read all the time.  When the store is larger than the 256 MiB Infinity
+// Cache, non-temporal loads keep the once-only traffic from evicting theta from the 4 MiB L2 of
+// each XCD (its gathers are the L2-request-bound part of the kernel): C3 0.244 -> 0.226 ms.  A
+// store that fits the Infinity Cache (C2, or one shard of an 8-GPU run) is faster with ordinary
+// loads (0.0348 vs 0.0387 ms), so the policy is a template flag chosen per store.
+template <bool kNT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+    return kNT ? __builtin_nontemporal_load(p) : *p;
+}
+
 // LDS window entries are addressed by byte offset (the 16-bit codes are stored
 // pre-multiplied by 8), which saves the shift per alignment.
 __device__ __forceinline__ double lds_ld(const double *base, uint32_t byte_off)
@@ -60,7 +72,7 @@ struct SliceRegs {
 // address arithmetic.  Pairs are loaded together; the second element of the last
 // pair of an odd-width slice is the next slice's first alignment (the arrays are
 // padded by one row) and is zeroed.
-template <typename WT, int kCh>
+template <typename WT, int kCh, bool kNT = false>
 __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, uint32_t lane,
                                            uint32_t width)
@@ -68,9 +80,9 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
 #pragma unroll
     for (int g = 0; g < kCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            r.w[2 * g] = wbase[(2 * g) * 64 + lane];
-            r.w[2 * g + 1] = wbase[(2 * g + 1) * 64 + lane];
-            r.c[g] = cbase[g * 64 + lane];
+            r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
+            r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
         } else {
             r.w[2 * g] = (WT)0;
             r.w[2 * g + 1] = (WT)0;
@@ -164,7 +176,8 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kUpfront, int kSched>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kUpfront, int kSched,
+          bool kNT>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     SliceRegs<WT, kCh> R[kSets];
 #pragma unroll
     for (uint32_t q = 0; q < (kUpfront ? kPerWave : 1u); ++q)
-        load_slice(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+        load_slice<WT, kCh, kNT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -233,10 +246,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-                rt[k] = r_tid[o];
-                rw[k] = r_w[o];
-                rrow[k] = r_row[o];
-                rslot[k] = r_slot[o];
+                rt[k] = ld_stream<kNT>(&r_tid[o]);
+                rw[k] = ld_stream<kNT>(&r_w[o]);
+                rrow[k] = ld_stream<kNT>(&r_row[o]);
+                rslot[k] = ld_stream<kNT>(&r_slot[o]);
             }
 #pragma unroll
             for (int k = 0; k < kRem; ++k)
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     for (uint32_t q = 0; q < kPerWave; ++q) {
         const uint32_t s = wave + kWaves * q;
         if (!kUpfront && q + 1 < kPerWave)
-            load_slice(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+            load_slice<WT, kCh, kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
         if (s < td.n_slices)
             fold_slice<WT, kCh, kCopies, kSched>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
@@ -390,10 +403,22 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
 #else
     constexpr uint32_t ablate = 0;
 #endif
+    // matrix bytes one pass streams; beyond the Infinity Cache they are loaded non-temporally
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (sizeof(WT) + 2) + t.n_remote * (sizeof(WT) + 10);
+    static const int nt_policy = [] {
+        const char *e = getenv("OEM_TILE_NT"); // tuning knob: 0 never, 1 always, unset = by size
+        return e ? atoi(e) : -1;
+    }();
+    const bool nt = nt_policy < 0 ? stream_bytes > (192ull << 20) : nt_policy != 0;
+#define OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, NT)                                               \
+    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP, SC, NT>), dim3(t.n_tiles), dim3(TH), \
+                       0, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, \
+                       theta, cnt, state, row_w_perm, ablate, problems)
 #define OEM_TILE(CH, REM, TH, MW, NC, UP, SC)                                                      \
-    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP, SC>), dim3(t.n_tiles), dim3(TH), 0,  \
-                       s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot,             \
-                       t.queue, theta, cnt, state, row_w_perm, ablate, problems)
+    do {                                                                                           \
+        if (nt) OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, true);                                    \
+        else OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, false);                                      \
+    } while (0)
     switch (variant) {
     case 1: OEM_TILE(8, 3, 512, 2, 4, true, 4); break;   // all slices up front, 8 waves
     case 2: OEM_TILE(12, 6, 256, 2, 4, false, 4); break;
@@ -402,6 +427,7 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
     default: OEM_TILE(8, 6, 256, 2, 4, false, 5); break; // 4 waves, 4 slices each, one slice prefetched ahead
     }
 #undef OEM_TILE
+#undef OEM_TILE_NT
 }
 
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
