@@ -181,6 +181,12 @@ int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint32_t *tid, f
  * OEM_ERR_STATE. */
 int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width, double growth_rate,
                                double *out_cov_prob);
+/* The single-cell coverage model: same bins and the same per-read normalisation, but the bin
+ * probabilities are binomial_continuous_prob's (src/util/binomial_probability.rs:7-224; called per
+ * cell at src/single_cell.rs:132-137): Binomial pmf of each bin's count, counts rescaled so the
+ * largest is 709, normalised over the transcript's bins.  ln_gamma is libm's lgamma (the reference
+ * uses statrs' Lanczos evaluation of the same function). */
+int oem_builder_coverage_probs_binomial(const oem_builder *b, uint32_t bin_width, double *out_cov_prob);
 /* Uploads the built store (oem_store_create on the builder's arrays). */
 int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
                              const oem_store_opts *opts, oem_store **out);

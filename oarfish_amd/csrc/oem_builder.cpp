@@ -149,11 +149,58 @@ extern "C" int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint3
 // coverage model (bulk): oarfish_types.rs:460-538, logistic_probability.rs:7-79,
 // normalize_probability.rs:5-74
 // ---------------------------------------------------------------------------
-extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width_u, double growth_rate,
-                                          double *out)
+// binomial_probability (binomial_probability.rs:7-168): per-bin Binomial(sum, p_i) pmf at the bin's
+// count after rescaling the counts so that the largest is 709, normalised over the bins.  The f32 /
+// f64 mix of the reference is kept (f32 sums and differences, f64 logs).  ln_gamma: statrs' Lanczos
+// evaluation there, libm's lgamma here (same function, ~1e-15 relative apart).
+static int binomial_probability(const std::vector<float> &cnt, const std::vector<float> &len, double distinct_rate,
+                                std::vector<double> &out)
+{
+    const size_t n = cnt.size();
+    const double kZero = 1e-20, kMaxScale = 709.0;
+    out.assign(n, 0.0);
+    float count_sum = 0.0f;
+    for (float c : cnt) count_sum += c;                                // :14
+    if (count_sum == 0.0f || distinct_rate == 0.0) return OEM_OK;      // :19-25
+    std::vector<double> p(n);
+    for (size_t i = 0; i < n; ++i)                                     // :27-43
+        p[i] = (cnt[i] == 0.0f || len[i] == 0.0f) ? 0.0 : (double)cnt[i] / ((double)len[i] * distinct_rate);
+    float max_val = std::nanf("");                                     // :50 (f32::max ignores a NaN operand)
+    for (float c : cnt) max_val = std::isnan(max_val) ? c : (std::isnan(c) ? max_val : std::max(max_val, c));
+    if (std::isnan(max_val)) return fail(OEM_ERR_STATE, "binomial_probability: max bin count is NaN (assert, :51)");
+    std::vector<float> m(n);
+    for (size_t i = 0; i < n; ++i)                                     // :61-71
+        m[i] = cnt[i] == max_val ? (float)kMaxScale : (float)(((double)cnt[i] * kMaxScale) / (double)max_val);
+    float sum_vec = 0.0f;
+    for (float v : m) sum_vec += v;                                    // :72
+    const double ln1 = std::lgamma((double)sum_vec + 1.0);             // :75
+    double total = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        const double denom = std::lgamma((double)m[i] + 1.0) + std::lgamma((double)(sum_vec - m[i]) + 1.0); // :76-79
+        const double num2 = (p[i] > kZero ? std::log(p[i]) : std::log(kZero)) * (double)m[i];              // :82
+        const double q = 1.0 - p[i];
+        const double num3 = (q > kZero ? std::log(q) : std::log(kZero)) * (double)(sum_vec - m[i]);        // :89
+        const double res = std::exp(ln1 - denom + num2 + num3);        // :101
+        if (std::isnan(num2) || std::isinf(num2) || std::isnan(num3) || std::isinf(num3) || std::isnan(res) ||
+            std::isinf(res))                                           // the reference panics (:83-112)
+            return fail(OEM_ERR_STATE, "binomial_probability: non-finite value at bin %zu", i);
+        out[i] = res;
+        total += res;                                                  // :120
+    }
+    for (size_t i = 0; i < n; ++i) {
+        out[i] /= total;                                               // :124
+        if (std::isnan(out[i])) return fail(OEM_ERR_STATE, "binomial_probability: normalised probability is NaN (:125-133)");
+    }
+    return OEM_OK;
+}
+
+enum class CovModel { Logistic, Binomial };
+
+static int coverage_probs_impl(const oem_builder *b, uint32_t bin_width_u, CovModel model, double growth_rate,
+                               double *out)
 {
     if (!b || (!out && !b->tid.empty())) return fail(OEM_ERR_ARG, "oem_builder_coverage_probs: NULL argument");
-    if (bin_width_u == 0) return fail(OEM_ERR_ARG, "coverage model with 0 bin width is not implemented (logistic_probability.rs:59)");
+    if (bin_width_u == 0) return fail(OEM_ERR_ARG, "coverage model with 0 bin width is not implemented (logistic_probability.rs:59, binomial_probability.rs:192)");
     const size_t T = b->txp_len.size(), nnz = b->tid.size();
     struct Txp { std::vector<double> bins, prob; double total_weight = 0.0, lenf = 0.0; };
     std::vector<Txp> txps(T);
@@ -187,12 +234,12 @@ extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_wid
         }
         tx.total_weight += 1.0;                                        // :537 (weight 1.0, :727)
     }
-    // logistic_prob (logistic_probability.rs:41-79)
+    // logistic_prob (logistic_probability.rs:41-79) / binomial_continuous_prob (binomial_probability.rs:170-224)
     for (size_t t = 0; t < T; ++t) {
         Txp &tx = txps[t];
         const size_t n = tx.bins.size();
         if (n == 0) return fail(OEM_ERR_STATE, "transcript %zu has no coverage bins", t); // assert (:54)
-        const double min_cov = tx.total_weight / 100.;                 // :55
+        const double min_cov = tx.total_weight / 100.;                 // :55 / binomial :180
         for (double &e : tx.bins) e += min_cov;                        // :56
         // get_normalized_counts_and_lengths (oarfish_types.rs:471-493): f32 counts; the bin-width
         // assertion is reproduced because the reference would panic there
@@ -201,9 +248,21 @@ extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_wid
             const float bs = (float)bi * bwf, be = std::min(((float)bi + 1.0f) * bwf, (float)tx.lenf);
             if (!(be > bs)) return fail(OEM_ERR_STATE, "transcript %zu: degenerate coverage bin %zu (assert, oarfish_types.rs:490)", t, bi);
         }
+        tx.prob.assign(n, 0.0);
+        if (model == CovModel::Binomial) {
+            std::vector<float> cnt(n), len(n);
+            for (size_t bi = 0; bi < n; ++bi) {
+                cnt[bi] = (float)tx.bins[bi];
+                len[bi] = std::min(((float)bi + 1.0f) * bwf, (float)tx.lenf) - (float)bi * bwf;
+            }
+            double distinct_rate = 0.0;                                // binomial_probability.rs:184-188
+            for (size_t bi = 0; bi < n; ++bi) distinct_rate += (double)cnt[bi] / (double)len[bi];
+            const int rc = binomial_probability(cnt, len, distinct_rate, tx.prob);
+            if (rc != OEM_OK) return rc;
+            continue;
+        }
         double count_sum = 0.0;                                        // logstic_function (:13-39)
         for (double e : tx.bins) count_sum += (double)(float)e;
-        tx.prob.assign(n, 0.0);
         if (count_sum <= 1e-8) continue;                               // :21-23
         const double expected = count_sum / (double)n;                 // :27
         for (size_t bi = 0; bi < n; ++bi) {
@@ -248,6 +307,16 @@ extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_wid
         for (uint64_t j = b->row_ptr[r]; j < b->row_ptr[r + 1]; ++j) out[j] /= denom; // :65-69
     }
     return OEM_OK;
+}
+
+extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width, double growth_rate, double *out)
+{
+    return coverage_probs_impl(b, bin_width, CovModel::Logistic, growth_rate, out);
+}
+
+extern "C" int oem_builder_coverage_probs_binomial(const oem_builder *b, uint32_t bin_width, double *out)
+{
+    return coverage_probs_impl(b, bin_width, CovModel::Binomial, 0.0, out);
 }
 
 extern "C" int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,

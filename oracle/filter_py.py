@@ -126,7 +126,42 @@ def _rust_round(x):  # f64::round: half away from zero
     return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
 
 
-def coverage_probs(st: Store, txp_len, bin_width: int, growth_rate: float):
+def _f32(x):
+    return float(np.float32(x))
+
+
+def binomial_probability(cnt, length, distinct_rate):
+    """binomial_probability.rs:7-168 with its f32 / f64 mix (cnt, length: f32 values held as floats)."""
+    n = len(cnt)
+    ZERO, MAXS = 1e-20, 709.0
+    count_sum = np.float32(0.0)
+    for c in cnt:
+        count_sum = np.float32(count_sum + np.float32(c))                    # :14 (f32 sum)
+    if float(count_sum) == 0.0 or distinct_rate == 0.0:                      # :19-25
+        return [0.0] * n
+    p = [0.0 if (c == 0.0 or l == 0.0) else c / (l * distinct_rate) for c, l in zip(cnt, length)]  # :27-43
+    max_val = max(cnt)                                                        # :50
+    m = [_f32(MAXS) if c == max_val else _f32((c * MAXS) / max_val) for c in cnt]  # :61-71
+    sum_vec = np.float32(0.0)
+    for v in m:
+        sum_vec = np.float32(sum_vec + np.float32(v))                        # :72
+    sum_vec = float(sum_vec)
+    ln1 = math.lgamma(sum_vec + 1.0)                                         # :75
+    res = []
+    for pi, mi in zip(p, m):
+        rest = _f32(np.float32(sum_vec) - np.float32(mi))                    # (sum_vec - count) in f32
+        denom = math.lgamma(mi + 1.0) + math.lgamma(rest + 1.0)              # :76-79
+        num2 = (math.log(pi) if pi > ZERO else math.log(ZERO)) * mi          # :82
+        q = 1.0 - pi
+        num3 = (math.log(q) if q > ZERO else math.log(ZERO)) * rest          # :89
+        res.append(math.exp(ln1 - denom + num2 + num3))                      # :101
+    tot = 0.0
+    for r in res:
+        tot += r                                                             # :120
+    return [r / tot for r in res]                                            # :121-137
+
+
+def coverage_probs(st: Store, txp_len, bin_width: int, growth_rate: float, model: str = "logistic"):
     T = len(txp_len)
     bins = [[0.0] * int(math.ceil(float(txp_len[t]) / float(bin_width))) for t in range(T)]
     total_weight = [0.0] * T
@@ -150,6 +185,15 @@ def coverage_probs(st: Store, txp_len, bin_width: int, growth_rate: float):
         min_cov = total_weight[t] / 100.0
         b = [e + min_cov for e in bins[t]]
         counts = [float(np.float32(e)) for e in b]               # f32 counts (oarfish_types.rs:478)
+        if model == "binomial":                                  # binomial_continuous_prob (:170-196)
+            n = len(b)
+            bwf = np.float32(_rust_round(float(txp_len[t]) / float(n)))
+            lens = [_f32(min(np.float32((np.float32(i) + np.float32(1.0)) * bwf), np.float32(float(txp_len[t])))
+                         - np.float32(np.float32(i) * bwf)) for i in range(n)]       # oarfish_types.rs:479-484
+            rate = 0.0
+            for c, l in zip(counts, lens):
+                rate += c / l                                     # :184-188
+            prob.append(binomial_probability(counts, lens, rate)); continue
         csum = 0.0
         for c in counts:
             csum += c

@@ -166,6 +166,68 @@ def test_coverage_model_matches_python_restatement(seed, bin_width, growth):
     _lib.lib().oem_builder_destroy(h)
 
 
+@pytest.mark.parametrize("seed,bin_width", [(15, 100), (16, 50), (17, 250)])
+def test_binomial_coverage_model_matches_python_restatement(seed, bin_width):
+    """The single-cell coverage model (binomial_continuous_prob, binomial_probability.rs:7-224, hook
+    single_cell.rs:132-137): same bins and read normalisation, binomial bin probabilities with the
+    reference's f32/f64 mix.  Same operation order, libm lgamma here, CPython's own Lanczos lgamma there (as statrs has its own): 1e-9."""
+    rng = np.random.default_rng(seed)
+    T = 30
+    txp_len = rng.integers(400, 4000, size=T)
+    F = fp.Filters()
+    h = _builder(F, txp_len)
+    ref = fp.Store()
+    for _ in range(1200):
+        t0 = int(rng.integers(0, T))
+        g = []
+        for j in range(int(rng.integers(1, 4))):
+            t = int((t0 + j) % T)
+            L = int(txp_len[t])
+            start = int(rng.integers(0, max(1, L - 120)))
+            end = int(rng.integers(start + 100, L + 1)) if start + 100 <= L else L
+            span = end - start
+            g.append(fp.Rec(t, start, end, span, 2000 - int(rng.integers(0, 40)) * (j > 0), 1000 if span >= 600 else max(span, 1)))
+        assert _add(h, g) == fp.add_group(ref, F, txp_len, g)
+    rp, tid, p, s, e, sd, dt = _export(h)
+    cov = np.zeros(len(tid), dtype=np.float64)
+    _lib.check(_lib.lib().oem_builder_coverage_probs_binomial(h, bin_width, cov.ctypes.data))
+    want = np.asarray(fp.coverage_probs(ref, txp_len, bin_width, 0.0, model="binomial"))
+    np.testing.assert_allclose(cov, want, rtol=1e-9, atol=1e-300)
+    sums = np.add.reduceat(cov, rp[:-1].astype(np.int64))
+    live = sums > 0
+    np.testing.assert_allclose(sums[live], 1.0, rtol=1e-12)
+    assert live.mean() > 0.9 and len(np.unique(np.round(cov, 6))) > 50
+    assert _lib.lib().oem_builder_coverage_probs_binomial(h, 0, cov.ctypes.data) == _lib.OEM_ERR_ARG
+    _lib.lib().oem_builder_destroy(h)
+
+
+def test_binomial_probability_against_scipy():
+    """Pins the restatement of binomial_probability.rs to an independent evaluation: after the 709
+    rescale, bin i gets Binomial(n = sum of rescaled counts, p_i) pmf at its rescaled count
+    (gamma-function form), normalised over the bins."""
+    from scipy.special import gammaln
+    rng = np.random.default_rng(3)
+    cnt = [float(np.float32(x)) for x in rng.uniform(0.2, 40.0, size=17)]
+    length = [100.0] * 16 + [37.0]
+    rate = sum(c / l for c, l in zip(cnt, length))
+    got = np.asarray(fp.binomial_probability(cnt, length, rate))
+    c = np.asarray(cnt); l = np.asarray(length)
+    p = c / (l * rate)
+    m32 = (c * 709.0 / c.max()).astype(np.float32)                  # the reference holds these as f32
+    n32 = np.float32(0.0)
+    for v in m32:
+        n32 = np.float32(n32 + v)
+    m, n, rest = m32.astype(np.float64), float(n32), (n32 - m32).astype(np.float64)
+    logpmf = gammaln(n + 1) - gammaln(m + 1) - gammaln(rest + 1) + m * np.log(p) + rest * np.log1p(-p)
+    want = np.exp(logpmf); want /= want.sum()
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-300)
+    # and the f32 roundings move the result by well under the 1e-4 budget of the abundances
+    m, n = c * 709.0 / c.max(), (c * 709.0 / c.max()).sum()
+    exact = np.exp(gammaln(n + 1) - gammaln(m + 1) - gammaln(n - m + 1) + m * np.log(p) + (n - m) * np.log1p(-p))
+    np.testing.assert_allclose(got, exact / exact.sum(), rtol=5e-3)
+    assert fp.binomial_probability([0.0, 0.0], [100.0, 100.0], 0.0) == [0.0, 0.0]
+
+
 @pytest.mark.gpu
 def test_records_to_abundances_with_coverage_model():
     """End to end on the device: alignment records -> filters -> as_prob, coverage model -> cov_prob,

@@ -264,6 +264,53 @@ def test_aux_counts_and_assignment_probs(coverage):
     assert np.all(got[:2] == -1.0) and got[2] == 1.0
 
 
+@pytest.mark.parametrize("threads", [3, 8])
+def test_bulk_tail_writes_reference_files(tmp_path, threads):
+    """bulk.rs:131-207 from the built store onwards: em/em_par by thread count, aux counts, the
+    `.quant` / `.ambig_info.tsv` / `.infreps.pq` / `.prob` files; every number against the oracle."""
+    import pyarrow.parquet as pq
+    from oarfish_amd.bulk import BulkArgs, perform_inference_and_write_output
+    st = synth.make_store(30_000, 2_000, seed=77)
+    store = InMemoryAlignmentStore.from_arrays(st.row_ptr, st.tid, st.as_prob)
+    names = [f"ENST{i:08d}.1" for i in range(st.n_txps)]
+    lens = (500 + np.arange(st.n_txps) % 3000).tolist()
+    rnames = [f"read/{i}" for i in range(st.n_reads)]
+    out = str(tmp_path / "res" / "sample")
+    args = BulkArgs(output=out, threads=threads, num_bootstraps=2, write_assignment_probs=True,
+                    display_thresh=1e-4, seed=5)
+    counts = perform_inference_and_write_output(store, names, lens, args, read_names=rnames)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    want, wi = (c_oracle.em_par if threads > 4 else c_oracle.do_em)(o, max_iter=1000, conv_thresh=1e-3)
+    assert_counts_close(counts, want, st.n_reads, st.n_txps)
+    # .quant: header + one line per transcript, counts printed Rust-style and parsing back exactly
+    q = open(out + ".quant").read().split("\n")
+    assert q[0] == "tname\tlen\tnum_reads" and len(q) == st.n_txps + 2
+    qc = np.array([float(l.split("\t")[2]) for l in q[1:-1]])
+    assert np.array_equal(qc, counts) and q[1].split("\t")[:2] == [names[0], str(lens[0])]
+    wu, wt = c_oracle.aux_counts(o)
+    amb = np.loadtxt(out + ".ambig_info.tsv", skiprows=1, dtype=np.int64)
+    assert np.array_equal(amb[:, 0], wu) and np.array_equal(amb[:, 2], wt) and np.array_equal(amb[:, 1], wt - wu)
+    breps = pq.read_table(out + ".infreps.pq").to_pandas().to_numpy().T
+    assert breps.shape == (2, st.n_txps)
+    np.testing.assert_allclose(breps.sum(axis=1), st.n_reads, rtol=1e-9)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        for b in range(2):                                     # same device resample -> oracle EM
+            w = d.bootstrap_weights(5, b)
+            wb, _ = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, row_w=w)
+            assert_counts_close(breps[b], wb, st.n_reads, st.n_txps)
+    wp = c_oracle.assignment_probs(o, counts, 1e-4)
+    lines = open(out + ".prob").read().split("\n")
+    assert lines[0] == f"{st.n_txps}\t{st.n_reads}" and lines[1:st.n_txps + 1] == names
+    for r in (0, 1, 17, st.n_reads - 1):
+        f = lines[st.n_txps + 1 + r].split("\t")
+        b, e = int(st.row_ptr[r]), int(st.row_ptr[r + 1])
+        keep = wp[b:e] >= 0
+        n = int(f[1])
+        assert f[0] == rnames[r] and n == keep.sum()
+        assert [int(x) for x in f[2:2 + n]] == st.tid[b:e][keep].tolist()
+        np.testing.assert_allclose([float(x) for x in f[2 + n:]], wp[b:e][keep], atol=0.5001e-4)
+
+
 def test_ragged_store_with_repeated_transcripts():
     """Reads that hit the same transcript twice, empty reads, zero weights, a 100-alignment read."""
     rng = np.random.default_rng(77)
