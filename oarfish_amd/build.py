@@ -6,9 +6,13 @@ gfx950 code objects without a GPU, so this runs in the CPU-only container too.
 from __future__ import annotations
 
 import os
-import shutil
-import subprocess
 import sys
+
+if __name__ == "__main__" and sys.path and os.path.abspath(sys.path[0]) == os.path.dirname(os.path.abspath(__file__)):
+    sys.path.pop(0)  # run as a script: keep this package's types.py from shadowing the stdlib module
+
+import shutil      # noqa: E402
+import subprocess  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -56,6 +60,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip"]
     if os.environ.get("OEM_TILE_ABLATION"):  # profiling builds only: enables the OEM_TILE_ABLATE switches
         cmd.append("-DOEM_TILE_ABLATION")
+        if os.environ.get("OEM_ABL_BYTEW"):
+            cmd.append("-DOEM_ABL_BYTEW")
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp", "-ldl"]
     if verbose:

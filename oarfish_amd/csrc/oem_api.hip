@@ -32,6 +32,7 @@ int fail(int code, const char *fmt, ...)
 
 int comm_rank(const Comm *c);
 int comm_size(const Comm *c);
+bool comm_exchanges(const Comm *c);
 
 namespace {
 
@@ -111,7 +112,7 @@ int prepare_row_w(oem_store *s, const RunArgs &a)
 int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
 {
     OEM_TRY(enqueue_pass(s, a, s->d_state));
-    if (s->comm && comm_size(s->comm) > 1)
+    if (comm_exchanges(s->comm))
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, p.n_txps, s->stream));
     OEM_TRY(launch_reldiff_swap_clear(s, s->theta, s->cnt, s->d_state, p));
     return OEM_OK;
@@ -151,7 +152,7 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
 
     OEM_TRY(launch_zero_small(s, s->theta, s->cnt, T));                                  // em.rs:238-242
     OEM_TRY(enqueue_pass(s, a, nullptr));                                                 // em.rs:245-252
-    if (s->comm && comm_size(s->comm) > 1)
+    if (comm_exchanges(s->comm))
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
     if (info) {
         info->niter = s->h_state->niter;
@@ -251,7 +252,7 @@ int run_bootstrap_batch(oem_store *s, uint32_t b0, uint32_t nb, uint64_t seed, c
     OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
     EmParams p{T, max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, conv_thresh};
     if (max_iter == 0) return fail(OEM_ERR_ARG, "batched bootstrap needs max_iter >= 1");
-    const bool sharded = s->comm && comm_size(s->comm) > 1;
+    const bool sharded = comm_exchanges(s->comm);
     uint32_t launched = 0;
     const uint32_t total = max_iter + 1; // loop passes + the final one
     while (launched < total) {
@@ -521,7 +522,7 @@ extern "C" int oem_m_step(oem_store *s, const double *theta, const uint32_t *row
     a.row_end = s->csr.n_reads;
     OEM_TRY(prepare_row_w(s, a));
     OEM_TRY(enqueue_pass(s, a, nullptr));
-    if (s->comm && comm_size(s->comm) > 1)
+    if (comm_exchanges(s->comm))
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
     return copy_counts_out(s, out_counts);
 }

@@ -82,7 +82,7 @@ struct Comm {
 
 int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
 {
-    if (!c || c->n_ranks == 1) {
+    if (!c || !c->comm) { // no exchange partner
         if (send != recv)
             OEM_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
         return OEM_OK;
@@ -94,6 +94,7 @@ int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t cou
 
 int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }
+bool comm_exchanges(const Comm *c) { return c && c->comm; }
 
 } // namespace oem
 
@@ -124,7 +125,9 @@ extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int
     c->rank = rank;
     c->n_ranks = n_ranks;
     c->device = device;
-    if (n_ranks > 1) {
+    // n_ranks == 1 with a unique id still builds a real RCCL communicator (RCCL accepts one rank):
+    // the single-GPU self test of the dlopen'ed entry points.  n_ranks == 1 without one is a no-op.
+    if (n_ranks > 1 || unique_id) {
         if (!unique_id) { delete c; return fail(OEM_ERR_ARG, "oem_comm_create: unique_id is NULL"); }
         int rc = load_rccl();
         if (rc != OEM_OK) { delete c; return rc; }

@@ -80,8 +80,17 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
 #pragma unroll
     for (int g = 0; g < kCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
-            r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+#ifdef OEM_ABL_BYTEW // timing experiment: one byte per weight (values are garbage)
+            if constexpr (sizeof(WT) == 4) {
+                const uint16_t b = ld_stream<kNT>(&reinterpret_cast<const uint16_t *>(wbase)[g * 64 + lane]);
+                r.w[2 * g] = __uint_as_float(b & 255u);
+                r.w[2 * g + 1] = __uint_as_float((uint32_t)b >> 8);
+            } else
+#endif
+            {
+                r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
+                r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            }
             r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
         } else {
             r.w[2 * g] = (WT)0;
@@ -114,6 +123,12 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     WT wz[kCh];
 #pragma unroll
     for (int k = 0; k < kCh; ++k) wz[k] = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : cur.w[k];
+#ifdef OEM_ABL_BYTEW
+    if constexpr (sizeof(WT) == 4) {
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) wz[k] = reinterpret_cast<const float *>(theta_l)[__float_as_uint(cur.w[k]) & 255u];
+    }
+#endif
     if (ablate & 16) { // timing experiment: consume the operands, nothing else
         float acc = 0.f;
 #pragma unroll

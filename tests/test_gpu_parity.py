@@ -388,6 +388,28 @@ def test_row_shard_semantics_single_rank():
         comm.close()
 
 
+def test_rccl_entry_points_with_one_rank_communicator():
+    """The dlopen'ed RCCL entry points (ncclGetUniqueId / ncclCommInitRank / ncclAllReduce f64 sum on
+    the store's stream / ncclCommDestroy) exercised for real with a ONE-rank communicator -- all a
+    1-GPU box allows; with it attached every pass runs the all-reduce and results must not move."""
+    from oarfish_amd import dist as odist
+    st = synth.make_store(60_000, 4_000, seed=301)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        base, bi = d.em_run(None, 300, 1e-3, 1)
+        w = np.stack([d.bootstrap_weights(9, b) for b in range(2)])
+        bbase, _ = d.bootstrap(2, seed=9, row_w_all=w, max_iter=200)
+        comm = odist.create_comm(0, 1, 0)                         # real RCCL communicator of size 1
+        try:
+            d.attach_comm(comm.handle, st.n_reads, 0)
+            got, gi = d.em_run(None, 300, 1e-3, 1)
+            assert gi.niter == bi.niter
+            np.testing.assert_allclose(got, base, rtol=1e-9, atol=1e-9)
+            bgot, _ = d.bootstrap(2, seed=9, row_w_all=w, max_iter=200)
+            np.testing.assert_allclose(bgot, bbase, rtol=1e-9, atol=1e-9)
+        finally:
+            comm.close()
+
+
 def test_edge_cases():
     # empty store: every count 0
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:
