@@ -335,7 +335,28 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     t.n_rows = h.n_rows;
     t.n_local = h.n_local;
     t.n_remote = h.n_remote;
-    OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
+    {
+        // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Descriptors are stored so that each
+        // XCD walks one contiguous eighth of the tiles: neighbouring tiles share theta-window lines
+        // and the partially filled queue lines at their run boundaries, which then meet in one L2.
+        static const int xcd_map = [] {
+            const char *e = getenv("OEM_TILE_XCD"); // tuning knob: 0 = descriptor order as built
+            return e ? atoi(e) : 0;
+        }();
+        if (xcd_map > 0 && h.n_tiles >= 64) {
+            const uint32_t n = h.n_tiles, nx = (uint32_t)xcd_map, chunk = (n + nx - 1) / nx;
+            std::vector<TileDesc> re;
+            re.reserve(n);
+            // position b holds tile (b % nx) * chunk + b / nx; positions whose tile does not exist are skipped
+            for (uint32_t b = 0; re.size() < n; ++b) {
+                const uint64_t ti = (uint64_t)(b % nx) * chunk + b / nx;
+                if (ti < n) re.push_back(h.tiles[ti]);
+            }
+            OEM_TRY(upload_vec(&t.tiles, re, &s->hbm_bytes));
+        } else {
+            OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
+        }
+    }
     OEM_TRY(upload_vec(&t.perm, h.perm, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.codes, h.codes, &s->hbm_bytes));
     if (s->csr.w_is_f64) {
@@ -756,6 +777,54 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     return rc;
 }
 
+// One group of consecutive cells [c0, c1): batched on the device when it can be (every pass over the
+// resident store serves all unfinished cells), otherwise cell after cell over the caller-order CSR.
+int run_cells_group(const uint64_t *cell_row_off, uint32_t c0, uint32_t c1, const uint64_t *row_ptr,
+                    const uint32_t *tid, const float *as_prob, const double *cov_prob, uint32_t n_txps, int device,
+                    uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos)
+{
+    const uint32_t n_cells = c1 - c0;
+    const uint64_t r0 = cell_row_off[c0], r1 = cell_row_off[c1];
+    const uint64_t a0 = row_ptr[r0], a1 = row_ptr[r1];
+    const uint64_t n_reads = r1 - r0, nnz = a1 - a0;
+    std::vector<uint64_t> off(n_cells + 1), rp(n_reads + 1);
+    for (uint32_t c = 0; c <= n_cells; ++c) off[c] = cell_row_off[c0 + c] - r0;
+    for (uint64_t r = 0; r <= n_reads; ++r) rp[r] = row_ptr[r0 + r] - a0;
+    const uint32_t *tid_g = tid ? tid + a0 : nullptr;
+    const float *p_g = as_prob ? as_prob + a0 : nullptr;
+    const double *cov_g = cov_prob ? cov_prob + a0 : nullptr;
+    double *out_g = out + (uint64_t)c0 * n_txps;
+    oem_run_info *infos_g = infos ? infos + c0 : nullptr;
+
+    static const bool serial_cells = getenv("OEM_SERIAL_CELLS") != nullptr; // A/B knob
+    if (!serial_cells) {
+        bool used = false;
+        int rcb = run_cells_batched(off.data(), n_cells, rp.data(), tid_g, p_g, cov_g, n_reads, nnz, n_txps, device,
+                                    max_iter, conv_thresh, out_g, infos_g, &used);
+        if (rcb != OEM_OK || used) return rcb;
+    }
+    // fallback (max_iter == 0 or a single cell): cells one after another
+    oem_store *s = nullptr;
+    oem_store_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    opts.reorder_rows = 1; // cells are row ranges of the caller-order CSR
+    OEM_TRY(oem_store_create(rp.data(), tid_g, p_g, cov_g, n_reads, nnz, n_txps, device, &opts, &s));
+    int rc = OEM_OK;
+    for (uint32_t c = 0; c < n_cells && rc == OEM_OK; ++c) {
+        RunArgs a;
+        a.row_begin = off[c];
+        a.row_end = off[c + 1];
+        a.total_reads = a.row_end - a.row_begin; // the cell's own store.len() (single_cell.rs:122-130)
+        a.max_iter = max_iter;
+        a.conv_thresh = conv_thresh;
+        a.min_iter_gate = 50;                    // em::em (single_cell.rs:150)
+        rc = run_em_device(s, a, infos_g ? &infos_g[c] : nullptr);
+        if (rc == OEM_OK) rc = copy_counts_out(s, out_g + (uint64_t)c * n_txps);
+    }
+    free_store(s);
+    return rc;
+}
+
 } // namespace
 } // namespace oem
 
@@ -780,34 +849,30 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         if (row_ptr[i + 1] < row_ptr[i]) return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu", (unsigned long long)i);
     if (row_ptr[0] != 0 || row_ptr[n_reads] != nnz) return fail(OEM_ERR_ARG, "oem_em_run_cells: row_ptr must span [0, nnz]");
 
-    // batched on the device: every pass over the resident store serves all unfinished cells
-    static const bool serial_cells = getenv("OEM_SERIAL_CELLS") != nullptr; // A/B knob
-    if (!serial_cells) {
-        bool used = false;
-        int rcb = run_cells_batched(cell_row_off, n_cells, row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps,
-                                    device, max_iter, conv_thresh, out, infos, &used);
-        if (rcb != OEM_OK || used) return rcb;
+    // Cells are independent problems, so a large experiment is cut into groups of consecutive cells
+    // that bound the batched store (transcript space < 2^32, <= 2^30 alignments, and the layout
+    // builder's tile x bucket table); each group is one batched run on the device.
+    const char *group_env = getenv("OEM_CELLS_GROUP_NNZ"); // tuning / test knob, read per call
+    const uint64_t max_group_nnz = group_env ? (uint64_t)atoll(group_env) : (1ull << 30);
+    uint32_t c0 = 0;
+    while (c0 < n_cells) {
+        uint32_t c1 = c0 + 1;
+        while (c1 < n_cells) {
+            const uint64_t cells = (uint64_t)(c1 + 1 - c0);
+            const uint64_t reads = cell_row_off[c1 + 1] - cell_row_off[c0];
+            const uint64_t gnnz = row_ptr[cell_row_off[c1 + 1]] - row_ptr[cell_row_off[c0]];
+            const uint64_t buckets = (cells * n_txps + kBucket - 1) / kBucket;
+            const uint64_t tiles_est = reads / 256 + 2 * cells;
+            if (cells * n_txps >= (1ull << 32) || reads >= (1ull << 32) || gnnz > max_group_nnz ||
+                tiles_est * buckets > (1ull << 28))
+                break;
+            ++c1;
+        }
+        OEM_TRY(run_cells_group(cell_row_off, c0, c1, row_ptr, tid, as_prob, cov_prob, n_txps, device, max_iter,
+                                conv_thresh, out, infos));
+        c0 = c1;
     }
-    // fallback (max_iter == 0, one cell, or a transcript space beyond 2^32): cells one after another
-    oem_store *s = nullptr;
-    oem_store_opts opts;
-    std::memset(&opts, 0, sizeof(opts));
-    opts.reorder_rows = 1; // cells are row ranges of the caller-order CSR
-    OEM_TRY(oem_store_create(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, &opts, &s));
-    int rc = OEM_OK;
-    for (uint32_t c = 0; c < n_cells && rc == OEM_OK; ++c) {
-        RunArgs a;
-        a.row_begin = cell_row_off[c];
-        a.row_end = cell_row_off[c + 1];
-        a.total_reads = a.row_end - a.row_begin; // the cell's own store.len() (single_cell.rs:122-130)
-        a.max_iter = max_iter;
-        a.conv_thresh = conv_thresh;
-        a.min_iter_gate = 50;                    // em::em (single_cell.rs:150)
-        rc = run_em_device(s, a, infos ? &infos[c] : nullptr);
-        if (rc == OEM_OK) rc = copy_counts_out(s, out + (uint64_t)c * n_txps);
-    }
-    free_store(s);
-    return rc;
+    return OEM_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -206,9 +206,13 @@ def test_cells_match_per_cell_oracle():
         assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
 
 
-def test_cells_ragged_batch():
+@pytest.mark.parametrize("group_nnz", [None, 30_000])
+def test_cells_ragged_batch(group_nnz, monkeypatch):
     """Cells of very different sizes (incl. an empty one and a one-read one), with the coverage column:
-    every cell stops at its own iteration."""
+    every cell stops at its own iteration.  With a small group bound the experiment is cut into several
+    batched groups (and single-cell groups take the cell-by-cell path): results must not depend on it."""
+    if group_nnz:
+        monkeypatch.setenv("OEM_CELLS_GROUP_NNZ", str(group_nnz))
     T = 900
     rng = np.random.default_rng(12)
     sizes = [4000, 0, 1, 700, 2500, 60]
