@@ -425,9 +425,13 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
         return e ? atoi(e) : -1;
     }();
     const bool nt = nt_policy < 0 ? stream_bytes > (192ull << 20) : nt_policy != 0;
+    static const uint32_t pad_lds = [] {
+        const char *e = getenv("OEM_TILE_PAD_LDS"); // occupancy experiment: extra (unused) LDS bytes per workgroup
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
 #define OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, NT)                                               \
     hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP, SC, NT>), dim3(t.n_tiles), dim3(TH), \
-                       0, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, \
+                       pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, \
                        theta, cnt, state, row_w_perm, ablate, problems)
 #define OEM_TILE(CH, REM, TH, MW, NC, UP, SC)                                                      \
     do {                                                                                           \
