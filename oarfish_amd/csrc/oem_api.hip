@@ -5,11 +5,13 @@
 //   bulk.rs:155-159   em::em / em::em_par      -> oem_em_run
 //   bulk.rs:178-194   em::bootstrap            -> oem_bootstrap
 //   single_cell.rs:139-160  per-cell em::em    -> oem_em_run_cells
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "oem_internal.h"
@@ -35,6 +37,19 @@ int comm_size(const Comm *c);
 bool comm_exchanges(const Comm *c);
 
 namespace {
+
+// OEM_VERBOSE=1: wall-clock breakdown of store creation on stderr (upload / layout diagnostics)
+struct StageTimer {
+    bool on = getenv("OEM_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[oem] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 int ensure_device(int device)
 {
@@ -319,8 +334,8 @@ void free_store(oem_store *s)
     delete s;
 }
 
-template <typename T>
-int upload_vec(T **dst, const std::vector<T> &v, uint64_t *acct)
+template <typename T, typename A>
+int upload_vec(T **dst, const std::vector<T, A> &v, uint64_t *acct)
 {
     OEM_TRY(dev_alloc(dst, v.size(), acct));
     if (!v.empty()) OEM_HIP(hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
@@ -383,6 +398,7 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
                       int device, const oem_store_opts *opts, oem_store *s)
 {
     s->device = device;
+    StageTimer tm;
     OEM_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     DeviceCsr &m = s->csr;
     m.n_reads = n_reads;
@@ -391,51 +407,76 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     m.wide_ptr = nnz >= (1ull << 32);
     m.w_is_f64 = cov_prob != nullptr;
 
-    if (m.wide_ptr) {
-        uint64_t *d = nullptr;
-        OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
-        m.row_ptr = d;
-        OEM_HIP(hipMemcpy(d, row_ptr, sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice));
-    } else {
-        std::vector<uint32_t> rp(n_reads + 1);
-        for (uint64_t i = 0; i <= n_reads; ++i) rp[i] = (uint32_t)row_ptr[i];
-        uint32_t *d = nullptr;
-        OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
-        m.row_ptr = d;
-        OEM_HIP(hipMemcpy(d, rp.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice));
-    }
-    OEM_TRY(dev_alloc(&m.tid, nnz, &s->hbm_bytes));
-    OEM_HIP(hipMemcpy(m.tid, tid, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
-    if (m.w_is_f64) {
-        // em.rs:107-111: prev * (p as f64) * cov; w = (p as f64) * cov is the
-        // iteration-invariant factor (SURVEY.md 8a note 2: f64 keeps strict parity).
-        std::vector<double> w(nnz);
-        for (uint64_t j = 0; j < nnz; ++j) w[j] = (double)as_prob[j] * cov_prob[j];
-        OEM_TRY(dev_alloc(&m.w64, nnz, &s->hbm_bytes));
-        OEM_HIP(hipMemcpy(m.w64, w.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-    } else {
-        OEM_TRY(dev_alloc(&m.w32, nnz, &s->hbm_bytes));
-        OEM_HIP(hipMemcpy(m.w32, as_prob, sizeof(float) * nnz, hipMemcpyHostToDevice));
-    }
-    OEM_TRY(dev_alloc(&s->theta, n_txps, &s->hbm_bytes));
-    OEM_TRY(dev_alloc(&s->cnt, n_txps, &s->hbm_bytes));
-    OEM_TRY(dev_alloc(&s->d_state, 1, &s->hbm_bytes));
-    OEM_HIP(hipHostMalloc((void **)&s->h_state, sizeof(EmState), hipHostMallocDefault));
-    OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (n_txps ? n_txps : 1), hipHostMallocDefault));
+    // The caller-order CSR (row ranges of per-cell runs, aux counts, assignment probabilities) goes up
+    // from a helper thread while this one builds the tiled layout: both are host-bound.
+    auto upload_csr = [&]() -> int {
+        if (m.wide_ptr) {
+            uint64_t *d = nullptr;
+            OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
+            m.row_ptr = d;
+            OEM_HIP(hipMemcpy(d, row_ptr, sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice));
+        } else {
+            std::vector<uint32_t> rp(n_reads + 1);
+            for (uint64_t i = 0; i <= n_reads; ++i) rp[i] = (uint32_t)row_ptr[i];
+            uint32_t *d = nullptr;
+            OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
+            m.row_ptr = d;
+            OEM_HIP(hipMemcpy(d, rp.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice));
+        }
+        OEM_TRY(dev_alloc(&m.tid, nnz, &s->hbm_bytes));
+        OEM_HIP(hipMemcpy(m.tid, tid, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
+        if (m.w_is_f64) {
+            // em.rs:107-111: prev * (p as f64) * cov; w = (p as f64) * cov is the
+            // iteration-invariant factor (SURVEY.md 8a note 2: f64 keeps strict parity).
+            std::vector<double> w(nnz);
+            for (uint64_t j = 0; j < nnz; ++j) w[j] = (double)as_prob[j] * cov_prob[j];
+            OEM_TRY(dev_alloc(&m.w64, nnz, &s->hbm_bytes));
+            OEM_HIP(hipMemcpy(m.w64, w.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+        } else {
+            OEM_TRY(dev_alloc(&m.w32, nnz, &s->hbm_bytes));
+            OEM_HIP(hipMemcpy(m.w32, as_prob, sizeof(float) * nnz, hipMemcpyHostToDevice));
+        }
+        OEM_TRY(dev_alloc(&s->theta, n_txps, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&s->cnt, n_txps, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&s->d_state, 1, &s->hbm_bytes));
+        OEM_HIP(hipHostMalloc((void **)&s->h_state, sizeof(EmState), hipHostMallocDefault));
+        OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (n_txps ? n_txps : 1), hipHostMallocDefault));
+        return OEM_OK;
+    };
     s->global_n_reads = n_reads;
     s->global_row_offset = 0;
 
     // default: lay the store out in primary-sorted tiles (oem_layout.h)
     const uint32_t reorder = opts ? opts->reorder_rows : 0;
-    if (reorder != 1 && n_reads > 0) {
-        TiledHost h;
-        const char *err = nullptr;
-        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                               opts ? opts->problem_size : 0u)) {
-            OEM_TRY(upload_tiled(s, h));
-        } else if (reorder == 2) {
-            return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
+    if (reorder == 1 || n_reads == 0) {
+        OEM_TRY(upload_csr());
+        tm.lap("caller-order CSR upload");
+        return OEM_OK;
+    }
+    int csr_rc = OEM_OK;
+    char csr_err[sizeof(t_err)] = {0};
+    std::thread up([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            csr_rc = OEM_ERR_HIP;
+            snprintf(csr_err, sizeof(csr_err), "hipSetDevice(%d) failed in the upload thread", device);
+            return;
         }
+        csr_rc = upload_csr();
+        if (csr_rc != OEM_OK) snprintf(csr_err, sizeof(csr_err), "%s", t_err); // t_err is thread-local
+    });
+    TiledHost h;
+    const char *err = nullptr;
+    const bool tiled = build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
+                                          opts ? opts->problem_size : 0u);
+    tm.lap("tiled layout build (host)");
+    up.join();
+    tm.lap("wait for the CSR upload");
+    if (csr_rc != OEM_OK) return fail(csr_rc, "%s", csr_err);
+    if (tiled) {
+        OEM_TRY(upload_tiled(s, h));
+        tm.lap("tiled layout upload");
+    } else if (reorder == 2) {
+        return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
     }
     return OEM_OK;
 }
@@ -475,7 +516,9 @@ extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, co
     if (!row_ptr) return fail(OEM_ERR_ARG, "oem_store_create: row_ptr is NULL");
     if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_store_create: tid/as_prob is NULL");
     if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_store_create: n_txps is 0");
+    StageTimer tm;
     OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps));
+    tm.lap("validate_csr");
     OEM_TRY(ensure_device(device));
     oem_store *s = new (std::nothrow) oem_store();
     if (!s) return fail(OEM_ERR_OOM, "oem_store_create: host allocation failed");

@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace oem {
@@ -62,6 +65,14 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
         *err = "tiled layout needs n_reads < 2^32";
         return false;
     }
+    const bool verbose = getenv("OEM_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[oem]   layout: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_prev).count());
+        t_prev = t1;
+    };
     const uint32_t R = (uint32_t)n_reads;
     const uint32_t n_buckets = (n_txps + kBucket - 1) / kBucket;
     out->n_buckets = n_buckets;
@@ -104,6 +115,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     for (uint32_t t = 0; t < n_txps; ++t) hist[t + 1] += hist[t];
     out->n_rows = n_rows;
 
+    lap("anchors");
     // 2. stable counting sort of the non-empty reads by primary
     std::vector<uint32_t> order(n_rows);
     {
@@ -112,6 +124,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             if (key[r] != 0xffffffffu) order[cur[key[r]]++] = r;
     }
 
+    lap("counting sort");
     // 3. tile boundaries: <= kTileRows reads, primaries within the window
     std::vector<uint32_t> tile_start; // positions in `order`
     std::vector<uint32_t> tile_lo;
@@ -147,6 +160,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     out->tiles.assign(n_tiles, TileDesc{});
     out->perm.assign(n_rows, 0);
 
+    lap("tile cuts");
     // 4. pass 1 (parallel over tiles): order reads by local count, measure sizes
     std::vector<TileSizes> sizes(n_tiles);
     std::atomic<bool> too_wide{false};
@@ -197,6 +211,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
         *err = "a read has more than 255 alignments inside one tile window";
         return false;
     }
+    lap("pass 1 (sizes)");
     // 5. offsets
     uint64_t w_slots = 0, c_slots = 0, n_remote = 0;
     std::vector<uint64_t> w_base(n_tiles), c_base(n_tiles);
@@ -224,37 +239,57 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     }
     out->n_remote = n_remote;
     // one row of slack: the pair loads of an odd-width slice touch the next row
-    out->codes.assign((c_slots + 1) * 64, 0u);
-    if (cov_prob) out->w64.assign((w_slots + 1) * 64, 0.0);
-    else out->w32.assign((w_slots + 1) * 64, 0.0f);
-    out->r_tid.assign(n_remote, 0u);
-    if (cov_prob) out->r_w64.assign(n_remote, 0.0);
-    else out->r_w32.assign(n_remote, 0.0f);
-    out->r_row.assign(n_remote, 0);
-    out->r_slot.assign(n_remote, 0u);
-    out->q_dst.assign(n_remote, 0);
+    // (not zero-filled here: every tile clears and fills its own range in pass 2)
+    out->codes.resize((c_slots + 1) * 64);
+    if (cov_prob) out->w64.resize((w_slots + 1) * 64);
+    else out->w32.resize((w_slots + 1) * 64);
+    std::memset(out->codes.data() + c_slots * 64, 0, 64 * sizeof(uint32_t)); // the slack row
+    if (cov_prob) std::memset(out->w64.data() + w_slots * 64, 0, 64 * sizeof(double));
+    else std::memset(out->w32.data() + w_slots * 64, 0, 64 * sizeof(float));
+    out->r_tid.resize(n_remote);
+    if (cov_prob) out->r_w64.resize(n_remote);
+    else out->r_w32.resize(n_remote);
+    out->r_row.resize(n_remote);
+    out->r_slot.resize(n_remote);
+    out->q_dst.resize(n_remote);
     // bucket-major queue: slot_base(tile, b) = bucket_base[b] + remote alignments of earlier tiles in b
+    // (two row-major sweeps of the tile x bucket table)
     out->bucket_base.assign(n_buckets + 1, 0u);
     {
+        std::vector<uint64_t> run(n_buckets, 0);
+        for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+            const uint32_t *row = &cnt_tb[(size_t)ti * n_buckets];
+            for (uint32_t b = 0; b < n_buckets; ++b) run[b] += row[b];
+        }
         uint64_t acc = 0;
         for (uint32_t b = 0; b < n_buckets; ++b) {
             out->bucket_base[b] = (uint32_t)acc;
-            for (uint32_t ti = 0; ti < n_tiles; ++ti) {
-                uint32_t &c = cnt_tb[(size_t)ti * n_buckets + b];
-                const uint32_t n = c;
-                c = (uint32_t)acc; // becomes the slot base of (tile, bucket)
-                acc += n;
-            }
+            const uint64_t n = run[b];
+            run[b] = acc; // running slot base of the bucket
+            acc += n;
         }
         out->bucket_base[n_buckets] = (uint32_t)acc;
+        for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+            uint32_t *row = &cnt_tb[(size_t)ti * n_buckets];
+            for (uint32_t b = 0; b < n_buckets; ++b) {
+                const uint32_t n = row[b];
+                row[b] = (uint32_t)run[b]; // becomes the slot base of (tile, bucket)
+                run[b] += n;
+            }
+        }
     }
 
+    lap("offsets");
     // 6. pass 2 (parallel over tiles): fill slices and remote records
     std::atomic<uint64_t> n_local{0};
     parallel_for(n_tiles, [&](uint32_t ti) {
         const TileDesc &td = out->tiles[ti];
         const uint32_t lo = td.lo, win = td.win_len;
         uint64_t woff = w_base[ti], coff = c_base[ti];
+        // clear this tile's slices (padding lanes carry weight 0 and code 0; codes are OR-ed in)
+        std::memset(out->codes.data() + coff * 64, 0, (size_t)sizes[ti].c_slots * 64 * sizeof(uint32_t));
+        if (cov_prob) std::memset(out->w64.data() + woff * 64, 0, (size_t)sizes[ti].w_slots * 64 * sizeof(double));
+        else std::memset(out->w32.data() + woff * 64, 0, (size_t)sizes[ti].w_slots * 64 * sizeof(float));
         std::vector<RemoteRec> rem;
         rem.reserve(td.remote_cnt);
         uint64_t nl = 0;
@@ -330,6 +365,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
         }
     });
     out->n_local = n_local.load();
+    lap("pass 2 (fill)");
     return true;
 }
 

@@ -27,6 +27,12 @@
 
 #include <stdint.h>
 
+#include <sys/mman.h>
+
+#include <cstdlib>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace oem {
@@ -61,6 +67,38 @@ static_assert(kTileSlices == 16, "TileDesc::width is sized for 16 slices");
 // Slice data: weights w[(off + j) * 64 + lane], j < width; codes packed in pairs,
 // c[(coff + j/2) * 64 + lane] >> 16*(j&1) & 0xffff = 8 * (tid - lo) (an LDS byte offset).
 
+// The big arrays are resized without being zero-filled (a serial memset of ~1 GB at 10 M reads);
+// the layout pass writes every element it owns, padding included, from the thread that fills it.
+// Large blocks are 2 MiB-aligned and advised towards transparent huge pages: the first touch of a
+// fresh 4 KiB page from 100+ threads serialises in the kernel and dominated the fill pass.
+template <typename T>
+struct DefaultInitAlloc {
+    using value_type = T;
+    DefaultInitAlloc() = default;
+    template <typename U> DefaultInitAlloc(const DefaultInitAlloc<U> &) noexcept {}
+    template <typename U> struct rebind { using other = DefaultInitAlloc<U>; };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        void *p = nullptr;
+        if (bytes >= (4u << 20)) {
+            const size_t huge = 2u << 20;
+            p = std::aligned_alloc(huge, (bytes + huge - 1) / huge * huge);
+            if (p) madvise(p, bytes, MADV_HUGEPAGE);
+        } else {
+            p = std::malloc(bytes ? bytes : 1);
+        }
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) noexcept { std::free(p); }
+    template <typename U> bool operator==(const DefaultInitAlloc<U> &) const noexcept { return true; }
+    template <typename U> bool operator!=(const DefaultInitAlloc<U> &) const noexcept { return false; }
+    template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using RawVec = std::vector<T, DefaultInitAlloc<T>>;
+
 // Host-side result of the layout pass; all arrays are uploaded verbatim.
 struct TiledHost {
     uint32_t n_tiles = 0;
@@ -70,15 +108,15 @@ struct TiledHost {
     uint64_t n_remote = 0;  // remote alignments
     std::vector<TileDesc> tiles;
     std::vector<uint32_t> perm;     // permuted position -> original read index
-    std::vector<uint32_t> codes;    // packed pairs of 16-bit window codes
-    std::vector<float> w32;         // local weights (coverage off)
-    std::vector<double> w64;        // local weights (coverage on)
-    std::vector<uint32_t> r_tid;    // remote: transcript
-    std::vector<float> r_w32;       // remote: weight
-    std::vector<double> r_w64;
-    std::vector<uint16_t> r_row;    // remote: read index inside its tile
-    std::vector<uint32_t> r_slot;   // remote: slot in the bucket-major queue
-    std::vector<uint16_t> q_dst;    // queue order: transcript - bucket * kBucket
+    RawVec<uint32_t> codes;       // packed pairs of 16-bit window codes
+    RawVec<float> w32;               // local weights (coverage off)
+    RawVec<double> w64;             // local weights (coverage on)
+    RawVec<uint32_t> r_tid;       // remote: transcript
+    RawVec<float> r_w32;           // remote: weight
+    RawVec<double> r_w64;
+    RawVec<uint16_t> r_row;       // remote: read index inside its tile
+    RawVec<uint32_t> r_slot;     // remote: slot in the bucket-major queue
+    RawVec<uint16_t> q_dst;       // queue order: transcript - bucket * kBucket
     std::vector<uint32_t> bucket_base; // [n_buckets + 1]: queue range of every bucket
 };
 
