@@ -216,13 +216,32 @@ def main():
     if args.bootstraps > 0:
         if args.no_batch_bootstrap:
             store.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
-        sync()
-        tb = time.perf_counter()
-        _out, infos = store.bootstrap(args.bootstraps, seed=1, max_iter=1000, conv_thresh=1e-3)
-        sync()
-        tb = time.perf_counter() - tb
-        boots = dict(value=args.bootstraps / tb, unit="bootstraps/s", n=args.bootstraps,
-                     mean_passes=float(np.mean([i.n_passes for i in infos])))
+        if world == 1:
+            sync()
+            tb = time.perf_counter()
+            _out, infos = store.bootstrap(args.bootstraps, seed=1, max_iter=1000, conv_thresh=1e-3)
+            sync()
+            tb = time.perf_counter() - tb
+            boots = dict(value=args.bootstraps / tb, unit="bootstraps/s", n=args.bootstraps,
+                         mean_passes=float(np.mean([i.n_passes for i in infos])), mode="one GPU")
+        else:
+            # replica-parallel: replicates are independent EM runs (em.rs:303-309), so every rank holds
+            # the WHOLE store (1.5 GB of 288 GB) and runs its own replicates -- no collective
+            f_rp, f_tid, f_p, _, _ = make_shard(cfg, 0, 1)
+            with DeviceStore(f_rp, f_tid, f_p, None, cfg["n_txps"], device=local_rank) as full:
+                if args.no_batch_bootstrap:
+                    full.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
+                n_total = args.bootstraps * world
+                sync()
+                tb = time.perf_counter()
+                _b0, _out, infos = odist.bootstrap_replica_parallel(full, n_total, 1, rank, world)
+                sync()
+                tb = time.perf_counter() - tb
+            tt = torch.tensor([tb], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            boots = dict(value=n_total / float(tt.item()), unit="bootstraps/s", n=n_total,
+                         mean_passes=float(np.mean([i.n_passes for i in infos])),
+                         mode=f"replica-parallel over {world} GPUs, whole store on each, no collective")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,7 @@ OEM_ERR_NO_DEVICE = 5
 OEM_ERR_STATE = 6
 OEM_UNIQUE_ID_BYTES = 128
 OEM_OPT_BATCH_BOOTSTRAP = 1
+OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2
 
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [

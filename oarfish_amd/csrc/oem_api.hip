@@ -239,7 +239,8 @@ int run_bootstrap_batch(oem_store *s, uint32_t b0, uint32_t nb, uint64_t seed, c
             OEM_HIP(hipMemcpyAsync(dst, row_w_all + (size_t)(b0 + k) * R, sizeof(uint32_t) * R,
                                    hipMemcpyHostToDevice, s->stream));
         } else {
-            OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed, b0 + k));
+            OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed,
+                                             s->bootstrap_first_replica + b0 + k));
         }
     }
     OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
@@ -548,6 +549,10 @@ extern "C" int oem_store_set_option(oem_store *store, uint32_t option, uint64_t 
     std::lock_guard<std::mutex> lk(store->mu);
     switch (option) {
     case OEM_OPT_BATCH_BOOTSTRAP: store->batch_bootstrap = value != 0; return OEM_OK;
+    case OEM_OPT_BOOTSTRAP_FIRST_REPLICA:
+        if (value > 0xffffffffull) return fail(OEM_ERR_ARG, "oem_store_set_option: replica index out of range");
+        store->bootstrap_first_replica = (uint32_t)value;
+        return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_store_set_option: unknown option %u", option);
     }
 }
@@ -697,8 +702,8 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
             OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (uint64_t)b * R, sizeof(uint32_t) * R,
                                    hipMemcpyHostToDevice, s->stream));
         } else {
-            OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset,
-                                             s->global_n_reads, seed, b)); // em.rs:274-276
+            OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset, s->global_n_reads, seed,
+                                             s->bootstrap_first_replica + b)); // em.rs:274-276
         }
         RunArgs a;
         a.init = init_abundances;
@@ -729,6 +734,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
                       double *out, oem_run_info *infos, bool *used)
 {
     *used = false;
+    StageTimer tm;
     const uint64_t total_txps = (uint64_t)n_cells * n_txps;
     if (max_iter < 1 || n_cells < 2 || total_txps >= (1ull << 32) || n_reads >= (1ull << 32)) return OEM_OK;
     // transcripts of cell p -> [p*T, (p+1)*T)
@@ -747,11 +753,13 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     std::memset(&opts, 0, sizeof(opts));
     opts.reorder_rows = 2;
     opts.problem_size = n_txps;
+    tm.lap("cells: virtual transcript ids");
     int rc = oem_store_create(row_ptr, vt.data(), as_prob, cov_prob, n_reads, nnz, (uint32_t)total_txps, device,
                               &opts, &s);
     if (rc != OEM_OK) return rc;
     std::vector<uint32_t>().swap(vt);
     *used = true;
+    tm.lap("cells: store create");
 
     auto body = [&]() -> int {
         MultiBuffers &mb = s->multi;
@@ -798,6 +806,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
                 }
             }
             if (rc2 != OEM_OK) break;
+            tm.lap("cells: EM loop");
             if (hipMemcpy(out, mb.out, sizeof(double) * total_txps, hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemcpy(hs.data(), mb.state, sizeof(BatchState) * n_cells, hipMemcpyDeviceToHost) != hipSuccess) {
                 rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: result read-back failed");
@@ -816,7 +825,9 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
         return rc2;
     };
     rc = body();
+    tm.lap("cells: read-back");
     free_store(s);
+    tm.lap("cells: free");
     return rc;
 }
 

@@ -168,6 +168,7 @@ struct oem_store {
     double *h_pinned = nullptr;          // pinned staging, n_txps f64
     oem::BatchBuffers batch;             // lazily allocated by the batched bootstrap
     oem::MultiBuffers multi;             // per-cell batches
+    uint32_t bootstrap_first_replica = 0; // OEM_OPT_BOOTSTRAP_FIRST_REPLICA
     bool batch_bootstrap = true;         // OEM_OPT_BATCH_BOOTSTRAP (2 replicates per pass when applicable)
     // multi-GPU
     oem::Comm *comm = nullptr;

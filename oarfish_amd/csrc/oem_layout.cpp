@@ -18,9 +18,15 @@ namespace {
 template <typename F>
 void parallel_for(uint32_t n, F fn)
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 32) nt = 32;
+    static const unsigned nt_max = [] {
+        const char *e = getenv("OEM_HOST_THREADS"); // layout-build threads (default: all cores, at most 128)
+        unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        if (n == 0) n = 4;
+        if (!e && n > 128) n = 128;
+        return n;
+    }();
+    unsigned nt = nt_max;
+    if (nt > (n + 15) / 16) nt = (n + 15) / 16; // one chunk of 16 per thread at least
     if (n < 64 || nt == 1) {
         for (uint32_t i = 0; i < n; ++i) fn(i);
         return;

@@ -92,6 +92,27 @@ def em_rowsharded(local_m_step: Callable[[np.ndarray], np.ndarray],
     return out, niter, n_passes, converged, last_rel
 
 
+def replica_range(n_boot: int, rank: int, world: int) -> Tuple[int, int]:
+    """Replica-parallel bootstraps: replicates [b0, b1) of rank ``rank``.  The reference's
+    replicates are independent EM runs (em.rs:303-309), so N processes that each hold the WHOLE
+    store split them with no collective at all; only the final B x T matrix is gathered."""
+    return n_boot * rank // world, n_boot * (rank + 1) // world
+
+
+def bootstrap_replica_parallel(store, n_boot: int, seed: int, rank: int, world: int, init=None,
+                               max_iter: int = 1000, conv_thresh: float = 1e-3, allgather=None):
+    """``store``: a DeviceStore over the whole (un-sharded) alignment store, no communicator
+    attached.  Runs this rank's replicates; replica b draws the same device resample whichever
+    rank runs it.  ``allgather(array[n_local, T]) -> list of per-rank arrays`` (optional) assembles
+    the full B x T matrix in replica order; without it (b0, local replicates, infos) is returned."""
+    b0, b1 = replica_range(n_boot, rank, world)
+    out, infos = store.bootstrap(b1 - b0, seed=seed, init=init, max_iter=max_iter,
+                                 conv_thresh=conv_thresh, first_replica=b0)
+    if allgather is None:
+        return b0, out, infos
+    return np.concatenate([np.asarray(x).reshape(-1, out.shape[1]) for x in allgather(out)], axis=0), infos
+
+
 class Comm:
     """RAII wrapper of an ``oem_comm*``."""
 

@@ -158,7 +158,11 @@ class DeviceStore:
         return w
 
     def bootstrap(self, n_boot: int, seed: int = 0, row_w_all=None, init=None, max_iter=1000,
-                  conv_thresh=1e-3):
+                  conv_thresh=1e-3, first_replica: int = 0):
+        """n_boot replicates; replicate k uses the device resample of global replica
+        ``first_replica + k`` (a pure function of (seed, replica), so processes holding the same
+        store can split one set of replicates)."""
+        self.set_option(_lib.OEM_OPT_BOOTSTRAP_FIRST_REPLICA, int(first_replica))
         out = np.zeros((n_boot, self.n_txps), dtype=np.float64)
         infos = (_lib.RunInfoC * max(n_boot, 1))()
         wp = None

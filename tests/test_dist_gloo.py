@@ -88,6 +88,67 @@ def test_rowsharded_em_world2_matches_single_process():
         np.testing.assert_allclose(got[r][4]["boot"][0], wantb, rtol=1e-9, atol=1e-9)
 
 
+class _OracleStore:
+    """Stand-in for a DeviceStore in the replica-parallel host logic: replica b's resample is a pure
+    function of (seed, b), as the device's counter-based draw is."""
+
+    def __init__(self, st):
+        from oracle import c_oracle
+        self.c, self.st = c_oracle, st
+        self.o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+
+    def bootstrap(self, n_boot, seed=0, init=None, max_iter=1000, conv_thresh=1e-3, first_replica=0):
+        out, infos = np.zeros((n_boot, self.st.n_txps)), []
+        for k in range(n_boot):
+            rng = np.random.default_rng([seed, first_replica + k])
+            w = np.bincount(rng.integers(0, self.st.n_reads, self.st.n_reads), minlength=self.st.n_reads).astype(np.uint32)
+            out[k], info = self.c.do_em(self.o, init=init, max_iter=max_iter, conv_thresh=conv_thresh, row_w=w)
+            infos.append(info)
+        return out, infos
+
+
+def _replica_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = synth.make_store(6_000, 400, seed=8, threads=1)
+
+    def allgather(x):   # ragged: pad to the largest local count
+        n = torch.tensor([x.shape[0]]); ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        m = max(int(v) for v in ns)
+        buf = torch.zeros((m, x.shape[1]), dtype=torch.float64); buf[:x.shape[0]] = torch.from_numpy(x)
+        outs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        return [o[:int(k)].numpy() for o, k in zip(outs, ns)]
+
+    full, _ = odist.bootstrap_replica_parallel(_OracleStore(st), 5, 77, rank, world, max_iter=120, allgather=allgather)
+    q.put((rank, full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_parallel_bootstrap_world2_matches_single_process():
+    """Replicates split over 2 ranks with no collective, gathered in replica order = the 5 replicates
+    one process computes (uneven split 2 + 3)."""
+    assert [odist.replica_range(5, r, 2) for r in range(2)] == [(0, 2), (2, 5)]
+    assert [odist.replica_range(3, r, 8) for r in range(8)].count((0, 0)) >= 1   # more ranks than replicates
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    st = synth.make_store(6_000, 400, seed=8, threads=1)
+    want, _ = _OracleStore(st).bootstrap(5, seed=77, max_iter=120)
+    for r in range(2):
+        np.testing.assert_allclose(got[r], want, rtol=1e-12, atol=1e-12)
+
+
 def test_shard_bounds():
     rp = np.array([0, 10, 11, 12, 13, 14, 24], dtype=np.uint64)
     b = odist.shard_bounds_by_nnz(rp, 2)

@@ -392,6 +392,25 @@ def test_row_shard_semantics_single_rank():
         comm.close()
 
 
+def test_bootstrap_first_replica_splits_a_replicate_set():
+    """OEM_OPT_BOOTSTRAP_FIRST_REPLICA: replicates [b0, b1) computed by another process (replica-parallel
+    multi-GPU bootstraps) are the same replicates one process computes."""
+    from oarfish_amd import dist as odist
+    st = synth.make_store(50_000, 3_000, seed=410)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        allb, _ = d.bootstrap(5, seed=31, max_iter=300)
+        parts = []
+        for rank in range(3):
+            b0, out, infos = odist.bootstrap_replica_parallel(d, 5, 31, rank, 3, max_iter=300)
+            assert (b0, b0 + len(out)) == odist.replica_range(5, rank, 3)
+            parts.append(out)
+        again, _ = d.bootstrap(2, seed=31, max_iter=300)            # the option is per call
+    got = np.concatenate(parts, axis=0)
+    for b in range(5):   # batching pairs replicates differently in the two runs: fp order only
+        assert_counts_close(got[b], allb[b], st.n_reads, st.n_txps, RTOL, f"replica {b}")
+    assert_counts_close(again[1], allb[1], st.n_reads, st.n_txps, RTOL, "first_replica resets to 0")
+
+
 def test_rccl_entry_points_with_one_rank_communicator():
     """The dlopen'ed RCCL entry points (ncclGetUniqueId / ncclCommInitRank / ncclAllReduce f64 sum on
     the store's stream / ncclCommDestroy) exercised for real with a ONE-rank communicator -- all a
