@@ -454,6 +454,27 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
         tm.lap("caller-order CSR upload");
         return OEM_OK;
     }
+    // The layout is built on the device from the resident CSR (oem_layout_device.hip); the host
+    // builder (oem_layout.cpp, the specification) takes the stores that one does not, or all of them
+    // with OEM_LAYOUT_BUILD=host.
+    const char *lb = getenv("OEM_LAYOUT_BUILD");
+    if (!(lb && lb[0] == 'h')) {
+        OEM_TRY(upload_csr());
+        tm.lap("caller-order CSR upload");
+        bool built = false;
+        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, &built));
+        tm.lap("tiled layout build (device)");
+        if (built) return OEM_OK;
+        TiledHost h;
+        const char *err = nullptr;
+        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
+                               opts ? opts->problem_size : 0u)) {
+            OEM_TRY(upload_tiled(s, h));
+        } else if (reorder == 2) {
+            return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
+        }
+        return OEM_OK;
+    }
     int csr_rc = OEM_OK;
     char csr_err[sizeof(t_err)] = {0};
     std::thread up([&] {
@@ -566,6 +587,49 @@ extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint
         // nnz*(4 [tid] + 4|8 [w]) + (R+1)*4|8 [row_ptr] + 2*T*8 [theta read, cnt written]
         *algorithmic_bytes_per_pass = m.nnz * (4 + (m.w_is_f64 ? 8 : 4)) +
                                       (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) + 2ull * m.n_txps * 8;
+    return OEM_OK;
+}
+
+// Test hook (not in the public header): 64-bit hashes of the resident tiled layout, so that the
+// device-built layout can be checked element for element against the host-built one.
+// out[0..3] = n_tiles, n_rows, n_local, n_remote; out[4..13] = tiles, perm, codes, w, r_tid, r_w,
+// r_row, r_slot, q_dst, bucket_base; out[14] (if asked for) = 1 when the device built it; returns OEM_ERR_STATE when the store has no tiled layout.
+extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out)
+{
+    if (!s || !out || n_out < 14) return fail(OEM_ERR_ARG, "oem_debug_layout_hash: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    const DeviceTiled &t = s->tiled;
+    if (!t.present) return fail(OEM_ERR_STATE, "oem_debug_layout_hash: no tiled layout");
+    auto hash_dev = [&](const void *d, size_t bytes, uint64_t *h) -> int {
+        std::vector<uint64_t> buf((bytes + 7) / 8, 0);
+        if (bytes) OEM_HIP(hipMemcpy(buf.data(), d, bytes, hipMemcpyDeviceToHost));
+        uint64_t x = 0x9e3779b97f4a7c15ull ^ bytes;
+        for (uint64_t v : buf) { x ^= v; x *= 0xff51afd7ed558ccdull; x ^= x >> 29; }
+        *h = x;
+        return OEM_OK;
+    };
+    // array lengths follow from the descriptors: slices and remote records end with the last tile
+    uint64_t w_slots = 0, c_slots = 0;
+    if (t.n_tiles) {
+        TileDesc last;
+        OEM_HIP(hipMemcpy(&last, t.tiles + (t.n_tiles - 1), sizeof(last), hipMemcpyDeviceToHost));
+        w_slots = last.w_base; c_slots = last.c_base;
+        for (uint32_t i = 0; i < kTileSlices; ++i) { w_slots += last.width[i]; c_slots += (last.width[i] + 1u) / 2; }
+    }
+    out[0] = t.n_tiles; out[1] = t.n_rows; out[2] = t.n_local; out[3] = t.n_remote;
+    const size_t wsz = s->csr.w_is_f64 ? 8 : 4;
+    OEM_TRY(hash_dev(t.tiles, sizeof(TileDesc) * t.n_tiles, &out[4]));
+    OEM_TRY(hash_dev(t.perm, 4 * t.n_rows, &out[5]));
+    OEM_TRY(hash_dev(t.codes, 4 * (c_slots + 1) * 64, &out[6]));
+    OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.w64 : (const void *)t.w32, wsz * (w_slots + 1) * 64, &out[7]));
+    OEM_TRY(hash_dev(t.r_tid, 4 * t.n_remote, &out[8]));
+    OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.r_w64 : (const void *)t.r_w32, wsz * t.n_remote, &out[9]));
+    OEM_TRY(hash_dev(t.r_row, 2 * t.n_remote, &out[10]));
+    OEM_TRY(hash_dev(t.r_slot, 4 * t.n_remote, &out[11]));
+    OEM_TRY(hash_dev(t.q_dst, 2 * t.n_remote, &out[12]));
+    OEM_TRY(hash_dev(t.bucket_base, 4 * ((size_t)t.n_buckets + 1), &out[13]));
+    if (n_out > 14) out[14] = t.built_on_device ? 1 : 0;
     return OEM_OK;
 }
 

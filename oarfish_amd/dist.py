@@ -113,6 +113,38 @@ def bootstrap_replica_parallel(store, n_boot: int, seed: int, rank: int, world: 
     return np.concatenate([np.asarray(x).reshape(-1, out.shape[1]) for x in allgather(out)], axis=0), infos
 
 
+def cell_bounds_by_nnz(cell_row_off, row_ptr, world: int) -> List[Tuple[int, int]]:
+    """Per-cell EM over N GPUs: contiguous blocks of cells balanced by alignment count.  Cells are
+    independent problems (single_cell.rs:139-160), so there is no collective, only the final gather."""
+    cell_row_off = np.asarray(cell_row_off, dtype=np.uint64)
+    row_ptr = np.asarray(row_ptr, dtype=np.uint64)
+    n_cells = len(cell_row_off) - 1
+    cell_nnz_end = row_ptr[cell_row_off.astype(np.int64)]          # alignments before each cell boundary
+    total = int(cell_nnz_end[-1])
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cell_nnz_end, total * r // world, side="left"))
+        cuts.append(min(max(c, cuts[-1]), n_cells))
+    cuts.append(n_cells)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def em_cells_sharded(cell_row_off, row_ptr, tid, as_prob, cov_prob, n_txps: int, rank: int, world: int,
+                     max_iter: int = 1000, convergence_thresh: float = 1e-3, device: int = 0):
+    """This rank's block of cells through ``em_cells``: returns (c0, c1, counts[c1-c0, T], infos)."""
+    from .em import em_cells
+    cell_row_off = np.asarray(cell_row_off, dtype=np.uint64)
+    row_ptr = np.asarray(row_ptr, dtype=np.uint64)
+    c0, c1 = cell_bounds_by_nnz(cell_row_off, row_ptr, world)[rank]
+    r0, r1 = int(cell_row_off[c0]), int(cell_row_off[c1])
+    a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+    out, infos = em_cells(cell_row_off[c0:c1 + 1] - cell_row_off[c0], row_ptr[r0:r1 + 1] - row_ptr[r0],
+                          np.asarray(tid)[a0:a1], np.asarray(as_prob)[a0:a1],
+                          None if cov_prob is None else np.asarray(cov_prob)[a0:a1], n_txps,
+                          max_iter=max_iter, convergence_thresh=convergence_thresh, device=device)
+    return c0, c1, out, infos
+
+
 class Comm:
     """RAII wrapper of an ``oem_comm*``."""
 

@@ -149,6 +149,17 @@ def test_replica_parallel_bootstrap_world2_matches_single_process():
         np.testing.assert_allclose(got[r], want, rtol=1e-12, atol=1e-12)
 
 
+def test_cell_bounds_cover_all_cells_and_balance_alignments():
+    cell_off, row_ptr, tid, p = synth.make_cells(23, 400, 300, seed=5)
+    for world in (1, 2, 3, 8, 40):
+        b = odist.cell_bounds_by_nnz(cell_off, row_ptr, world)
+        assert b[0][0] == 0 and b[-1][1] == 23 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        nnz = [int(row_ptr[int(cell_off[c1])] - row_ptr[int(cell_off[c0])]) for c0, c1 in b]
+        assert sum(nnz) == len(tid)
+        if world <= 8:
+            assert max(nnz) <= len(tid) / world + 2 * len(tid) / 23   # within ~2 cells of the ideal share
+
+
 def test_shard_bounds():
     rp = np.array([0, 10, 11, 12, 13, 14, 24], dtype=np.uint64)
     b = odist.shard_bounds_by_nnz(rp, 2)

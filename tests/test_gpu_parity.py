@@ -206,6 +206,90 @@ def test_cells_match_per_cell_oracle():
         assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
 
 
+def _layout_hash(row_ptr, tid, p, cov, T, problem_size=0):
+    import ctypes as C
+    from oarfish_amd import _lib
+    opts = _lib.StoreOptsC()
+    opts.problem_size = problem_size
+    opts.reorder_rows = 2 if problem_size else 0
+    h = C.c_void_p()
+    row_ptr = np.ascontiguousarray(row_ptr, np.uint64); tid = np.ascontiguousarray(tid, np.uint32)
+    p = np.ascontiguousarray(p, np.float32)
+    cov = None if cov is None else np.ascontiguousarray(cov, np.float64)
+    _lib.check(_lib.lib().oem_store_create(row_ptr.ctypes.data, tid.ctypes.data, p.ctypes.data,
+                                           None if cov is None else cov.ctypes.data, len(row_ptr) - 1, len(tid), T, 0,
+                                           C.byref(opts), C.byref(h)))
+    out = (C.c_uint64 * 15)()
+    fn = _lib.lib().oem_debug_layout_hash
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    try:
+        _lib.check(fn(h, C.addressof(out), 15))
+    finally:
+        _lib.lib().oem_store_destroy(h)
+    return list(out)
+
+
+LAYOUT_FIELDS = ["n_tiles", "n_rows", "n_local", "n_remote", "tiles", "perm", "codes", "w", "r_tid", "r_w", "r_row",
+                 "r_slot", "q_dst", "bucket_base"]
+
+
+@pytest.mark.parametrize("case", ["medium", "coverage", "sparse_wide", "tiny", "empty_rows_dups", "cells", "c2"])
+def test_device_built_layout_equals_host_built_layout(case, monkeypatch):
+    """oem_layout_device.hip against its specification (oem_layout.cpp): every array of the tiled layout,
+    element for element (64-bit hashes of the resident arrays), over dense / sparse / ragged stores, the
+    f64 coverage weights and the per-cell problem boundaries."""
+    ps, cov = 0, None
+    if case == "medium":
+        st = synth.make_store(300_000, 20_000, seed=501); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    elif case == "coverage":
+        st = synth.make_store(120_000, 9_000, seed=502, coverage=True)
+        rp, tid, p, cov, T = st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps
+    elif case == "sparse_wide":   # few reads per transcript: window-limited tiles, many buckets
+        st = synth.make_store(60_000, 150_000, seed=503); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    elif case == "tiny":
+        st = synth.make_store(70, 40, seed=504, threads=1); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    elif case == "empty_rows_dups":
+        rng = np.random.default_rng(505)
+        T, lens = 5_000, rng.integers(0, 12, size=40_000)
+        lens[rng.random(len(lens)) < 0.1] = 0
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        base = np.repeat(rng.integers(0, T, size=len(lens)), lens)
+        tid = ((base + rng.integers(0, 6, size=int(rp[-1]))) % T).astype(np.uint32)      # repeats inside reads
+        p = np.exp(-rng.integers(0, 30, size=len(tid)) / 5.0).astype(np.float32)
+    elif case == "cells":
+        T = 3_000
+        cell_off, rp, tid, p = synth.make_cells(9, 2_500, T, seed=506)
+        tid = (tid.astype(np.uint64) + np.repeat(np.repeat(np.arange(9), np.diff(cell_off).astype(np.int64)),
+                                                  np.diff(rp).astype(np.int64)[:]) * T).astype(np.uint32)
+        ps, T = T, 9 * T
+    else:
+        st = synth.make_store(1_000_000, 60_000, seed=synth.BASE_SEED); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
+    want = _layout_hash(rp, tid, p, cov, T, ps)
+    monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")
+    got = _layout_hash(rp, tid, p, cov, T, ps)
+    assert want[14] == 0 and got[14] == 1, "the two builders were not the ones asked for"
+    diff = [f for f, a, b in zip(LAYOUT_FIELDS, got, want) if a != b]
+    assert not diff, f"{case}: device-built layout differs from the host-built one in {diff} ({got[:4]} vs {want[:4]})"
+    assert want[0] > 0
+
+
+def test_cells_sharded_over_ranks_equal_one_run():
+    """Per-cell EM over N GPUs = blocks of cells, no collective: the blocks of 3 ranks (run here one
+    after another on the one GPU) concatenate to the single run."""
+    from oarfish_amd import dist as odist
+    T = 700
+    cell_off, row_ptr, tid, p = synth.make_cells(11, 900, T, seed=21)
+    full, finfo = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=300)
+    parts, seen = [], []
+    for rank in range(3):
+        c0, c1, out, infos = odist.em_cells_sharded(cell_off, row_ptr, tid, p, None, T, rank, 3, max_iter=300)
+        parts.append(out); seen += list(range(c0, c1))
+        assert [i.niter for i in infos] == [i.niter for i in finfo[c0:c1]]
+    assert seen == list(range(11))
+    np.testing.assert_allclose(np.concatenate(parts, axis=0), full, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("group_nnz", [None, 30_000])
 def test_cells_ragged_batch(group_nnz, monkeypatch):
     """Cells of very different sizes (incl. an empty one and a one-read one), with the coverage column:
