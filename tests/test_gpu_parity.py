@@ -543,6 +543,42 @@ def test_edge_cases():
         assert_counts_close(cnt, g["runs"][0]["counts"], 1500, 200, 1e-10, "max_iter 0")
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_random_shapes_match_oracle(seed):
+    """Randomly shaped stores through the whole device path (device-built layout, tile + fold kernels,
+    loop state) against the oracle: read lengths 0..120 (beyond --best-n), tiny to wide transcript spaces,
+    repeated transcripts inside a read, zero and denormal weights, optional coverage column, random init,
+    both gates, point estimate + one injected bootstrap resample."""
+    rng = np.random.default_rng(9000 + seed)
+    R = int(rng.choice([1, 7, 300, 5_000, 40_000]))
+    T = int(rng.choice([1, 3, 40, 2_000, 70_000, 300_000]))
+    maxk = int(rng.choice([1, 3, 12, 120]))
+    lens = rng.integers(0, maxk + 1, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    base = np.repeat(rng.integers(0, T, size=R), lens)
+    spread = int(rng.choice([1, 8, 200, max(T, 1)]))
+    tid = ((base + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 60, size=nnz) / 5.0).astype(np.float32)
+    p[rng.random(nnz) < 0.03] = 0.0
+    p[rng.random(nnz) < 0.01] = np.float32(1e-42)                         # denormal
+    cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 3 == 0 else None
+    init = rng.gamma(1.0, R / max(T, 1) + 0.1, size=T) if seed % 4 == 1 else None
+    gate = 1 if seed % 2 else 50
+    o = c_oracle.Store(rp, tid, p, cov, T)
+    want, wi = c_oracle.do_em(o, init=init, max_iter=80, conv_thresh=1e-3, min_iter_gate=gate)
+    w = np.bincount(rng.integers(0, max(R, 1), size=R), minlength=R).astype(np.uint32)[:R]
+    wantb, wbi = c_oracle.do_em(o, max_iter=60, conv_thresh=1e-3, row_w=w)
+    with DeviceStore(rp, tid, p, cov, T) as d:
+        got, gi = d.em_run(init, 80, 1e-3, gate)
+        gotb, gbi = d.bootstrap(1, row_w_all=w[None, :], max_iter=60)
+    what = f"seed {seed}: R={R} T={T} maxk={maxk} spread={spread} cov={cov is not None} gate={gate}"
+    assert abs(gi.niter - wi.niter) <= 1, what
+    assert_counts_close(got, want, R, T, RTOL if gi.niter != wi.niter else 1e-9, what)
+    assert abs(gbi[0].niter - wbi.niter) <= 1, what
+    assert_counts_close(gotb[0], wantb, R, T, RTOL if gbi[0].niter != wbi.niter else 1e-9, what + " (bootstrap)")
+
+
 @pytest.mark.parametrize("tag", ["C", "I", "O"])
 def test_config0_sirv_shaped_store(tag):
     """BASELINE configs[0] on the device: SIRV annotation (69 / 44 / 100 transcripts), bulk mode,
