@@ -308,7 +308,8 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
 
 // rel-diff / swap / clear / state machine for kB replicates (em.rs:194-218, :238-254)
 //   curr_b[t] = cnt[t][b] + cnt2[b][t]
-__global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
+constexpr int kRelB = 1024; // as k_reldiff_swap_clear: few fat workgroups, the state-line atomics serialise
+__global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
                                                    double *__restrict__ cnt2, double *__restrict__ out,
                                                    BatchState *st, EmParams p)
 {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, d
             }
         }
     }
-    __shared__ double smax[256 / 64][kB];
+    __shared__ double smax[kRelB / 64][kB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void k_reldiff_b(double *__restrict__ theta, d
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
             double m = smax[0][b];
-            for (int i = 1; i < 256 / 64; ++i) m = fmax(m, smax[i][b]);
+            for (int i = 1; i < kRelB / 64; ++i) m = fmax(m, smax[i][b]);
             if (m > 0.0) atomicMax(&st[b].rel_bits, (unsigned long long)__double_as_longlong(m));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -476,8 +477,8 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 
 int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 {
-    const int grid = grid_for(p.n_txps, 256, 256);
-    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
+    const int grid = grid_for(p.n_txps, kRelB, 64);
+    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
     // (a replicate on its FINAL pass reads theta < 1e-5 as 0 inside k_em_tile_b: em.rs:238-242)
     OEM_HIP(hipGetLastError());
