@@ -543,6 +543,33 @@ def test_edge_cases():
         assert_counts_close(cnt, g["runs"][0]["counts"], 1500, 200, 1e-10, "max_iter 0")
 
 
+def test_store_lifecycle_returns_device_memory():
+    """Create / run / destroy cycles (point estimate, batched bootstrap, per-cell batch, a failed create)
+    must hand all HBM back: the scratch of the device layout builder included."""
+    import torch
+    st = synth.make_store(120_000, 9_000, seed=77)
+    cell_off, crp, ctid, cp = synth.make_cells(6, 3_000, 800, seed=3)
+
+    def cycle():
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+            d.em_run(None, 20, 0.0, 50)
+            d.bootstrap(3, seed=1, max_iter=20)
+            d.aux_counts()
+        oarfish_amd.em_cells(cell_off, crp, ctid, cp, None, 800, max_iter=20)
+        bad = st.tid.copy(); bad[5] = st.n_txps + 3
+        with pytest.raises(oarfish_amd.OemError):
+            DeviceStore(st.row_ptr, bad, st.as_prob, None, st.n_txps)
+
+    cycle()                                       # warm up allocator pools / code objects
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 8 cycles"
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_random_shapes_match_oracle(seed):
     """Randomly shaped stores through the whole device path (device-built layout, tile + fold kernels,
