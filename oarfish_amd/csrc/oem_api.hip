@@ -218,84 +218,100 @@ bool can_batch(const oem_store *s)
     return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0;
 }
 
-// nb (2..kBatch) bootstrap replicates, first global replica index b0, sharing every pass
-// over the matrix.  Returns OEM_OK and *fell_back = true (nothing written) if a multiplicity
-// does not fit a byte; the caller then runs these replicates one per pass.
-int run_bootstrap_batch(oem_store *s, uint32_t b0, uint32_t nb, uint64_t seed, const uint32_t *row_w_all,
-                        const double *init, uint32_t max_iter, double conv_thresh, double *out,
-                        oem_run_info *infos, bool *fell_back)
+// Rolling batch: kBatch slots share every pass over the matrix; a slot whose replicate has finished
+// is handed the next replicate at once, so both slots stay busy until the replicates run out (with
+// fixed pairs the pass count of a pair is the larger of the two, and every pair pays its own set-up).
+// Replicates whose multiplicities do not fit a byte are returned in `fallback` (one-per-pass path).
+int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all, const double *init,
+                          uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos,
+                          std::vector<uint32_t> *fallback)
 {
-    *fell_back = false;
     OEM_TRY(ensure_batch(s));
     BatchBuffers &bb = s->batch;
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
-    // resamples: injected, or drawn on the device (em.rs:274-276)
-    for (uint32_t k = 0; k < (uint32_t)kBatch; ++k) {
-        uint32_t *dst = bb.row_w_all + (size_t)k * R;
-        if (k >= nb) {
-            OEM_HIP(hipMemsetAsync(dst, 0, sizeof(uint32_t) * R, s->stream));
-        } else if (row_w_all) {
-            OEM_HIP(hipMemcpyAsync(dst, row_w_all + (size_t)(b0 + k) * R, sizeof(uint32_t) * R,
-                                   hipMemcpyHostToDevice, s->stream));
-        } else {
-            OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed,
-                                             s->bootstrap_first_replica + b0 + k));
-        }
-    }
-    OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
-    OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
-    uint32_t h_overflow = 0;
-    OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    OEM_HIP(hipStreamSynchronize(s->stream));
-    if (h_overflow) {
-        *fell_back = true;
-        return OEM_OK;
-    }
-    // theta init (em.rs:160-167; total_weight is the store's read count also for a replicate, em.rs:154)
     const double *d_init = nullptr;
     if (init) {
         OEM_HIP(hipMemcpyAsync(s->theta, init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
         d_init = s->theta;
     }
-    OEM_TRY(launch_batch_init_theta(s, bb, d_init, (double)s->global_n_reads / (double)T));
+    const double avg = (double)s->global_n_reads / (double)T; // em.rs:154: the store's read count also for a replicate
+    EmParams p{T, max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, conv_thresh};
+    const bool sharded = comm_exchanges(s->comm);
+    int slot_rep[kBatch];
+    uint32_t next = 0;
+    OEM_HIP(hipMemsetAsync(bb.row_w_all, 0, sizeof(uint32_t) * R * kBatch, s->stream));
     OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
-    for (uint32_t k = 0; k < (uint32_t)kBatch; ++k) {
-        BatchState &st = bb.h_state[k];
-        std::memset(&st, 0, sizeof(st));
-        st.phase = k < nb ? (max_iter == 0 ? kPhaseFinal : kPhaseRunning) : kPhaseFinished;
+    for (int k = 0; k < kBatch; ++k) {
+        slot_rep[k] = -1;
+        std::memset(&bb.h_state[k], 0, sizeof(BatchState));
+        bb.h_state[k].phase = kPhaseFinished;
     }
     OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
-    EmParams p{T, max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, conv_thresh};
-    if (max_iter == 0) return fail(OEM_ERR_ARG, "batched bootstrap needs max_iter >= 1");
-    const bool sharded = comm_exchanges(s->comm);
-    uint32_t launched = 0;
-    const uint32_t total = max_iter + 1; // loop passes + the final one
-    while (launched < total) {
-        uint32_t chunk = launched == 0 ? 52 : 16;
-        if (chunk > total - launched) chunk = total - launched;
-        for (uint32_t k = 0; k < chunk; ++k) {
+
+    // hands slot k the next replicate that fits (or leaves it idle when none is left)
+    auto load = [&](int k) -> int {
+        uint32_t *dst = bb.row_w_all + (size_t)k * R;
+        while (next < n_boot) {
+            const uint32_t rep = next++;
+            if (row_w_all) {
+                OEM_HIP(hipMemcpyAsync(dst, row_w_all + (size_t)rep * R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, s->stream));
+            } else {
+                OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed,
+                                                 s->bootstrap_first_replica + rep)); // em.rs:274-276
+            }
+            OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
+            OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
+            uint32_t h_overflow = 0;
+            OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+            OEM_HIP(hipStreamSynchronize(s->stream));
+            if (h_overflow) { // a multiplicity >= 256: this replicate goes to the one-per-pass path
+                fallback->push_back(rep);
+                OEM_HIP(hipMemsetAsync(dst, 0, sizeof(uint32_t) * R, s->stream));
+                OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
+                continue;
+            }
+            OEM_TRY(launch_batch_reset_slot(s, bb, d_init, avg, (uint32_t)k));
+            std::memset(&bb.h_state[k], 0, sizeof(BatchState));
+            bb.h_state[k].phase = kPhaseRunning;
+            OEM_HIP(hipMemcpyAsync(&bb.state[k], &bb.h_state[k], sizeof(BatchState), hipMemcpyHostToDevice, s->stream));
+            slot_rep[k] = (int)rep;
+            return OEM_OK;
+        }
+        return OEM_OK;
+    };
+    for (int k = 0; k < kBatch; ++k) OEM_TRY(load(k));
+
+    bool first = true;
+    for (;;) {
+        bool busy = false;
+        for (int k = 0; k < kBatch; ++k) busy = busy || slot_rep[k] >= 0;
+        if (!busy) break;
+        const uint32_t chunk = first ? 52u : 16u;
+        first = false;
+        for (uint32_t i = 0; i < chunk; ++i) {
             OEM_TRY(launch_batch_pass(s, bb));
             if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, 2 * (size_t)T * kBatch, s->stream));
             OEM_TRY(launch_batch_reldiff(s, bb, p));
         }
-        launched += chunk;
         OEM_HIP(hipMemcpyAsync(bb.h_state, bb.state, sizeof(BatchState) * kBatch, hipMemcpyDeviceToHost, s->stream));
         OEM_HIP(hipStreamSynchronize(s->stream));
-        bool all = true;
-        for (int k = 0; k < kBatch; ++k) all = all && bb.h_state[k].phase == kPhaseFinished;
-        if (all) break;
-    }
-    OEM_HIP(hipMemcpyAsync(bb.h_out, bb.out, sizeof(double) * T * kBatch, hipMemcpyDeviceToHost, s->stream));
-    OEM_HIP(hipStreamSynchronize(s->stream));
-    for (uint32_t k = 0; k < nb; ++k) {
-        std::memcpy(out + (size_t)(b0 + k) * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
-        if (infos) {
-            infos[b0 + k].niter = bb.h_state[k].niter;
-            infos[b0 + k].n_passes = bb.h_state[k].n_passes;
-            infos[b0 + k].converged = bb.h_state[k].converged;
-            infos[b0 + k].reserved = 0;
-            infos[b0 + k].rel_diff = bb.h_state[k].last_rel;
+        for (int k = 0; k < kBatch; ++k) {
+            if (slot_rep[k] < 0 || bb.h_state[k].phase != kPhaseFinished) continue;
+            const uint32_t rep = (uint32_t)slot_rep[k];
+            OEM_HIP(hipMemcpyAsync(bb.h_out + (size_t)k * T, bb.out + (size_t)k * T, sizeof(double) * T,
+                                   hipMemcpyDeviceToHost, s->stream));
+            OEM_HIP(hipStreamSynchronize(s->stream));
+            std::memcpy(out + (size_t)rep * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
+            if (infos) {
+                infos[rep].niter = bb.h_state[k].niter;
+                infos[rep].n_passes = bb.h_state[k].n_passes;
+                infos[rep].converged = bb.h_state[k].converged;
+                infos[rep].reserved = 0;
+                infos[rep].rel_diff = bb.h_state[k].last_rel;
+            }
+            slot_rep[k] = -1;
+            OEM_TRY(load(k));
         }
     }
     return OEM_OK;
@@ -748,20 +764,15 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
     OEM_TRY(ensure_row_w(s));
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
-    uint32_t b_first = 0;
-    if (s->batch_bootstrap && can_batch(s) && max_iter >= 1) {
-        // kBatch replicates share each pass over the matrix; a trailing single replicate
-        // runs on the one-replicate path below
-        while (n_boot - b_first >= 2) {
-            const uint32_t nb = n_boot - b_first >= (uint32_t)kBatch ? (uint32_t)kBatch : n_boot - b_first;
-            bool fell_back = false;
-            OEM_TRY(run_bootstrap_batch(s, b_first, nb, seed, row_w_all, init_abundances, max_iter,
-                                        conv_thresh, out, infos, &fell_back));
-            if (fell_back) break;
-            b_first += nb;
-        }
+    // the replicates that run one per pass: all of them, or those the rolling batch hands back
+    std::vector<uint32_t> single;
+    if (s->batch_bootstrap && can_batch(s) && max_iter >= 1 && n_boot >= 2) {
+        OEM_TRY(run_bootstrap_rolling(s, n_boot, seed, row_w_all, init_abundances, max_iter, conv_thresh, out, infos,
+                                      &single));
+    } else {
+        for (uint32_t b = 0; b < n_boot; ++b) single.push_back(b);
     }
-    for (uint32_t b = b_first; b < n_boot; ++b) {
+    for (uint32_t b : single) {
         if (row_w_all) {
             OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (uint64_t)b * R, sizeof(uint32_t) * R,
                                    hipMemcpyHostToDevice, s->stream));

@@ -403,6 +403,18 @@ __global__ __launch_bounds__(256) void k_init_theta_b(double *__restrict__ theta
     }
 }
 
+// (re)start of ONE slot of the rolling batch: theta[t][slot] = init / avg, its counts cleared
+__global__ __launch_bounds__(256) void k_reset_slot_b(double *__restrict__ theta, double *__restrict__ cnt,
+                                                      double *__restrict__ cnt2, const double *__restrict__ init,
+                                                      double avg, uint32_t n_txps, uint32_t slot)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
+        theta[(size_t)i * kB + slot] = init ? init[i] : avg;
+        cnt[(size_t)i * kB + slot] = 0.0;
+        cnt2[(size_t)slot * n_txps + i] = 0.0;
+    }
+}
+
 // multiplicities of kB replicates, caller order u32 [kB][R] -> tile order u8 [rows][kB];
 // *overflow is set if a multiplicity does not fit a byte (the caller then falls back to the
 // one-replicate-per-pass path)
@@ -490,6 +502,15 @@ int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *
     const int grid = grid_for(s->csr.n_txps, 256, 256);
     hipLaunchKernelGGL(k_init_theta_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, d_init, avg,
                        s->csr.n_txps);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot)
+{
+    const int grid = grid_for(s->csr.n_txps, 256, 256);
+    hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, d_init, avg,
+                       s->csr.n_txps, slot);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

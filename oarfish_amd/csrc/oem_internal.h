@@ -213,6 +213,7 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 int launch_batch_pass(oem_store *s, const BatchBuffers &bb);
 int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p);
 int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg);
+int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot);
 int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow);
 
 int launch_aux_counts(oem_store *s, uint32_t *d_unique, uint32_t *d_total);
