@@ -191,6 +191,18 @@ int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width, double 
  * largest is 709, normalised over the transcript's bins.  ln_gamma is libm's lgamma (the reference
  * uses statrs' Lanczos evaluation of the same function). */
 int oem_builder_coverage_probs_binomial(const oem_builder *b, uint32_t bin_width, double *out_cov_prob);
+/* Both coverage models on the device (oem_coverage_device.hip): the same f64 arithmetic, one thread per
+ * alignment / transcript / read; the bins are summed with f64 atomics, so results agree with the host
+ * functions above to the last few bits (and to ~1e-7 where a bin count sits on an f32 rounding boundary,
+ * the reference's f32 truncation of the counts, oarfish_types.rs:478).  model: 0 = logistic
+ * (growth_rate used), 1 = binomial.  Arrays are the caller's (host) CSR with the alignment coordinates
+ * AlnInfo carries (start / end, oarfish_types.rs:330-337); out_cov_prob: nnz f64. */
+int oem_coverage_probs_device(const uint64_t *row_ptr, const uint32_t *tid, const uint32_t *aln_start,
+                              const uint32_t *aln_end, const uint64_t *txp_len, uint64_t n_reads, uint64_t nnz,
+                              uint32_t n_txps, uint32_t bin_width, int model, double growth_rate, int device,
+                              double *out_cov_prob);
+int oem_builder_coverage_probs_device(const oem_builder *b, uint32_t bin_width, int model, double growth_rate,
+                                      int device, double *out_cov_prob);
 /* Uploads the built store (oem_store_create on the builder's arrays). */
 int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
                              const oem_store_opts *opts, oem_store **out);

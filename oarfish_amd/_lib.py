@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_set_option",
     "oem_builder_create", "oem_builder_destroy", "oem_builder_add_group", "oem_builder_dims",
     "oem_builder_discard_table", "oem_builder_export", "oem_builder_coverage_probs",
-    "oem_builder_coverage_probs_binomial", "oem_builder_store_create",
+    "oem_builder_coverage_probs_binomial", "oem_coverage_probs_device", "oem_builder_coverage_probs_device",
+    "oem_builder_store_create",
     "oem_m_step", "oem_em_run", "oem_aux_counts", "oem_assignment_probs",
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
@@ -117,6 +118,8 @@ def lib() -> C.CDLL:
     L.oem_builder_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.oem_builder_coverage_probs.argtypes = [vp, u32, f64, vp]
     L.oem_builder_coverage_probs_binomial.argtypes = [vp, u32, vp]
+    L.oem_coverage_probs_device.argtypes = [vp, vp, vp, vp, vp, u64, u64, u32, u32, i32, f64, i32, vp]
+    L.oem_builder_coverage_probs_device.argtypes = [vp, u32, i32, f64, i32, vp]
     L.oem_builder_store_create.argtypes = [vp, vp, i32, vp, C.POINTER(vp)]
     L.oem_m_step.argtypes = [vp, vp, vp, vp]
     L.oem_em_run.argtypes = [vp, vp, u32, f64, u32, vp, C.POINTER(RunInfoC)]

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "liboarfish_em.so")
 
-SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_builder.cpp", "oem_comm.cpp"]
+SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_coverage_device.hip", "oem_builder.cpp", "oem_comm.cpp"]
 HEADERS = ["oem_internal.h", "oem_layout.h", os.path.join(INCLUDE, "oarfish_em.h")]
 
 FLAGS = [

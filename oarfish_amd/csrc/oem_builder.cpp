@@ -319,6 +319,15 @@ extern "C" int oem_builder_coverage_probs_binomial(const oem_builder *b, uint32_
     return coverage_probs_impl(b, bin_width, CovModel::Binomial, 0.0, out);
 }
 
+extern "C" int oem_builder_coverage_probs_device(const oem_builder *b, uint32_t bin_width, int model, double growth_rate,
+                                                 int device, double *out)
+{
+    if (!b) return fail(OEM_ERR_ARG, "oem_builder_coverage_probs_device: builder is NULL");
+    return oem_coverage_probs_device(b->row_ptr.data(), b->tid.data(), b->start.data(), b->end.data(), b->txp_len.data(),
+                                     b->row_ptr.size() - 1, b->tid.size(), (uint32_t)b->txp_len.size(), bin_width, model,
+                                     growth_rate, device, out);
+}
+
 extern "C" int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
                                         const oem_store_opts *opts, oem_store **out)
 {

@@ -228,6 +228,64 @@ def test_binomial_probability_against_scipy():
     assert fp.binomial_probability([0.0, 0.0], [100.0, 100.0], 0.0) == [0.0, 0.0]
 
 
+def _synthetic_coordinates(rng, n_reads, T):
+    txp_len = rng.integers(400, 6000, size=T).astype(np.uint64)
+    lens = rng.integers(1, 9, size=n_reads)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    hot = (rng.random(n_reads) < 0.3) * 0 + (rng.random(n_reads) >= 0.3) * rng.integers(0, T, size=n_reads)  # 30 % of reads on transcript 0
+    tid = ((np.repeat(hot, lens) + np.concatenate([np.arange(k) for k in lens])) % T).astype(np.uint32)
+    L = txp_len[tid].astype(np.int64)
+    start = (rng.random(len(tid)) * np.maximum(L - 350, 1)).astype(np.int64)
+    end = np.minimum(start + rng.integers(100, 3000, size=len(tid)), L)
+    return txp_len, rp, tid, start.astype(np.uint32), end.astype(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,bin_width,growth", [(0, 100, 2.0), (0, 37, 0.7), (1, 100, 0.0), (1, 250, 0.0)])
+def test_device_coverage_model_matches_host(model, bin_width, growth):
+    """oem_coverage_probs_device against the host functions (same arithmetic; the bins are summed with
+    atomics, so agreement is to the last bits, loosened where a bin count sits on an f32 rounding
+    boundary), through a builder for the host side and raw arrays for the device side."""
+    rng = np.random.default_rng(40 + model)
+    T = 300
+    txp_len, rp, tid, start, end = _synthetic_coordinates(rng, 60_000, T)
+    nnz = len(tid)
+    got = np.zeros(nnz)
+    _lib.check(_lib.lib().oem_coverage_probs_device(rp.ctypes.data, tid.ctypes.data, start.ctypes.data, end.ctypes.data,
+                                                    txp_len.ctypes.data, len(rp) - 1, nnz, T, bin_width, model, growth, 0,
+                                                    got.ctypes.data))
+    # host side: the same store through the Python restatement's data model is slow at this size; use the
+    # C++ host functions via a builder filled without filtering
+    F = fp.Filters()
+    F.min_aligned_len, F.min_aligned_fraction, F.score_threshold = 0, 0.0, 0.0
+    h = _builder(F, txp_len)
+    recs = (_lib.AlnRecordC * 16)()
+    kept = C.c_uint32(0)
+    for r in range(len(rp) - 1):
+        b, e = int(rp[r]), int(rp[r + 1])
+        for q, j in enumerate(range(b, e)):
+            recs[q].ref_id, recs[q].aln_start, recs[q].aln_end = int(tid[j]), int(start[j]), int(end[j])
+            recs[q].aln_span, recs[q].score, recs[q].seq_len = int(end[j] - start[j]), 1000, int(end[j] - start[j])
+            recs[q].flags = _lib.REC_HAS_SCORE
+        _lib.check(_lib.lib().oem_builder_add_group(h, recs, e - b, C.byref(kept)))
+        assert kept.value == e - b
+    want = np.zeros(nnz)
+    if model == 0:
+        _lib.check(_lib.lib().oem_builder_coverage_probs(h, bin_width, growth, want.ctypes.data))
+    else:
+        _lib.check(_lib.lib().oem_builder_coverage_probs_binomial(h, bin_width, want.ctypes.data))
+    again = np.zeros(nnz)
+    _lib.check(_lib.lib().oem_builder_coverage_probs_device(h, bin_width, model, growth, 0, again.ctypes.data))
+    _lib.lib().oem_builder_destroy(h)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-300)
+    # typical agreement: rounding only (the binomial model exponentiates log-gammas of magnitude ~700)
+    assert np.median(np.abs(got - want) / np.maximum(want, 1e-300)) < (1e-12 if model == 0 else 1e-10)
+    np.testing.assert_allclose(again, got, rtol=2e-6, atol=1e-300)
+    assert _lib.lib().oem_coverage_probs_device(rp.ctypes.data, tid.ctypes.data, start.ctypes.data, end.ctypes.data,
+                                                txp_len.ctypes.data, len(rp) - 1, nnz, T, 0, model, growth, 0,
+                                                got.ctypes.data) == _lib.OEM_ERR_ARG
+
+
 @pytest.mark.gpu
 def test_records_to_abundances_with_coverage_model():
     """End to end on the device: alignment records -> filters -> as_prob, coverage model -> cov_prob,
