@@ -392,17 +392,6 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     }
 }
 
-// theta[t][b] = value (uniform init) or init[t]
-__global__ __launch_bounds__(256) void k_init_theta_b(double *__restrict__ theta, const double *__restrict__ init,
-                                                      double avg, uint32_t n_txps)
-{
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
-        const double v = init ? init[i] : avg;
-#pragma unroll
-        for (int b = 0; b < kB; ++b) theta[(size_t)i * kB + b] = v;
-    }
-}
-
 // (re)start of ONE slot of the rolling batch: theta[t][slot] = init / avg, its counts cleared
 __global__ __launch_bounds__(256) void k_reset_slot_b(double *__restrict__ theta, double *__restrict__ cnt,
                                                       double *__restrict__ cnt2, const double *__restrict__ init,
@@ -493,15 +482,6 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
     hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
     // (a replicate on its FINAL pass reads theta < 1e-5 as 0 inside k_em_tile_b: em.rs:238-242)
-    OEM_HIP(hipGetLastError());
-    return OEM_OK;
-}
-
-int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg)
-{
-    const int grid = grid_for(s->csr.n_txps, 256, 256);
-    hipLaunchKernelGGL(k_init_theta_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, d_init, avg,
-                       s->csr.n_txps);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

@@ -212,7 +212,6 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 // batched bootstrap (oem_batch_kernels.hip)
 int launch_batch_pass(oem_store *s, const BatchBuffers &bb);
 int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p);
-int launch_batch_init_theta(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg);
 int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot);
 int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow);
 
