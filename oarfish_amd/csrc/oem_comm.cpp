@@ -9,7 +9,10 @@
 // reused, so there is exactly one RCCL per process.
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <vector>
 
 #include "oem_internal.h"
 
@@ -73,15 +76,78 @@ const char *nccl_err(ncclResult_t r)
 
 } // namespace
 
+// Test backend (oem_debug_local_comm_create): the ranks are threads of ONE process that share a
+// GPU, and the "collective" is a host-side rendezvous plus one summing kernel.  It exists so that the
+// native sharded loop (global read count, per-pass exchange, identical stopping decision, sharded
+// bootstrap) runs with several real shards on a 1-GPU box, where RCCL refuses two ranks per device.
+struct LocalGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 0, arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const double *> send;
+    std::vector<double *> recv;
+    double *tmp = nullptr;
+    size_t tmp_count = 0;
+    ~LocalGroup() { hipFree(tmp); }
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+__global__ void k_local_sum(const double *const *send, int n, double *out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < n; ++r) s += send[r][i];
+        out[i] = s;
+    }
+}
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0;
     int n_ranks = 1;
     int device = 0;
+    std::shared_ptr<LocalGroup> local;
 };
+
+static int local_allreduce(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
+{
+    LocalGroup &g = *c->local;
+    OEM_HIP(hipStreamSynchronize(st)); // this rank's partial counts are complete
+    g.send[c->rank] = send;
+    g.recv[c->rank] = recv;
+    g.barrier();
+    int rc = OEM_OK;
+    if (c->rank == 0) {
+        do {
+            if (g.tmp_count < count) {
+                hipFree(g.tmp);
+                g.tmp = nullptr;
+                if (hipMalloc((void **)&g.tmp, count * sizeof(double)) != hipSuccess) { rc = fail(OEM_ERR_OOM, "local comm: scratch"); break; }
+                g.tmp_count = count;
+            }
+            const double **d_ptrs = nullptr;
+            if (hipMalloc((void **)&d_ptrs, sizeof(double *) * g.n) != hipSuccess) { rc = fail(OEM_ERR_OOM, "local comm: pointers"); break; }
+            hipMemcpy(d_ptrs, g.send.data(), sizeof(double *) * g.n, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_local_sum, dim3(256), dim3(256), 0, st, (const double *const *)d_ptrs, g.n, g.tmp, count);
+            for (int r = 0; r < g.n; ++r) hipMemcpyAsync(g.recv[r], g.tmp, count * sizeof(double), hipMemcpyDeviceToDevice, st);
+            if (hipStreamSynchronize(st) != hipSuccess) rc = fail(OEM_ERR_HIP, "local comm: sum failed");
+            hipFree(d_ptrs);
+        } while (false);
+    }
+    g.barrier(); // every rank's recv is written
+    return rc;
+}
 
 int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
 {
+    if (c && c->local) return local_allreduce(c, send, recv, count, st);
     if (!c || !c->comm) { // no exchange partner
         if (send != recv)
             OEM_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -94,7 +160,7 @@ int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t cou
 
 int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }
-bool comm_exchanges(const Comm *c) { return c && c->comm; }
+bool comm_exchanges(const Comm *c) { return c && (c->comm || c->local); }
 
 } // namespace oem
 
@@ -142,6 +208,26 @@ extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int
         if (r != 0) { delete c; return fail(OEM_ERR_RCCL, "ncclCommInitRank: %s", nccl_err(r)); }
     }
     *out = reinterpret_cast<oem_comm *>(c);
+    return OEM_OK;
+}
+
+// Test hook (not in the public header): n_ranks communicators of one process-local group.
+extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **out /* [n_ranks] */)
+{
+    if (n_ranks < 1 || !out) return fail(OEM_ERR_ARG, "oem_debug_local_comm_create: bad argument");
+    auto g = std::make_shared<LocalGroup>();
+    g->n = n_ranks;
+    g->send.assign(n_ranks, nullptr);
+    g->recv.assign(n_ranks, nullptr);
+    for (int r = 0; r < n_ranks; ++r) {
+        Comm *c = new (std::nothrow) Comm();
+        if (!c) return fail(OEM_ERR_OOM, "oem_debug_local_comm_create: host allocation failed");
+        c->rank = r;
+        c->n_ranks = n_ranks;
+        c->device = device;
+        c->local = g;
+        out[r] = reinterpret_cast<oem_comm *>(c);
+    }
     return OEM_OK;
 }
 

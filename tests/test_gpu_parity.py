@@ -495,6 +495,62 @@ def test_bootstrap_first_replica_splits_a_replicate_set():
     assert_counts_close(again[1], allb[1], st.n_reads, st.n_txps, RTOL, "first_replica resets to 0")
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_sharded_loop_with_several_shards_on_one_gpu(world):
+    """The native row-sharded loop (oem_em_run / oem_bootstrap on stores with an attached communicator)
+    with `world` real shards.  RCCL refuses two ranks per device, so the ranks are threads of this process
+    joined by the library's process-local test communicator (same call sites as RCCL: one sum of the count
+    vector per pass).  Results must equal the un-sharded store's and the oracle's, with identical iteration
+    counts on every rank."""
+    import ctypes as C
+    import threading
+    from oarfish_amd import _lib, dist as odist
+    st = synth.make_store(90_000, 6_000, seed=611)
+    handles = (C.c_void_p * world)()
+    fn = _lib.lib().oem_debug_local_comm_create
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    _lib.check(fn(world, 0, C.addressof(handles)))
+    res, errs = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, rank, world)
+            with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps) as d:
+                d.attach_comm(C.c_void_p(handles[rank]), st.n_reads, sh.row_begin)
+                cnt, info = d.em_run(None, 400, 1e-3, 50)
+                par, pinfo = d.em_run(None, 400, 1e-3, 1)
+                boots, binfo = d.bootstrap(3, seed=17, max_iter=200)
+                res[rank] = (cnt, info, par, pinfo, boots, binfo)
+        except Exception as e:  # pragma: no cover
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=240)
+    assert not errs and all(r is not None for r in res), errs
+    for r in range(world):
+        _lib.lib().oem_comm_destroy(C.c_void_p(handles[r]))
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    want, wi = c_oracle.do_em(o, max_iter=400, conv_thresh=1e-3)
+    wpar, wpi = c_oracle.do_em(o, max_iter=400, conv_thresh=1e-3, min_iter_gate=1)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as full:
+        wb = [c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3, row_w=full.bootstrap_weights(17, b)) for b in range(3)]
+    for r in range(world):
+        cnt, info, par, pinfo, boots, binfo = res[r]
+        assert info.niter == res[0][1].niter and pinfo.niter == res[0][3].niter          # same decision on every rank
+        assert np.array_equal(cnt, res[0][0]) and np.array_equal(boots, res[0][4])        # same reduced vector
+        assert abs(info.niter - wi.niter) <= 1 and abs(pinfo.niter - wpi.niter) <= 1
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL if info.niter != wi.niter else 1e-9, f"rank {r} em")
+        assert_counts_close(par, wpar, st.n_reads, st.n_txps, RTOL if pinfo.niter != wpi.niter else 1e-9, f"rank {r} em_par")
+        for b in range(3):
+            assert abs(binfo[b].niter - wb[b][1].niter) <= 1
+            assert_counts_close(boots[b], wb[b][0], st.n_reads, st.n_txps,
+                                RTOL if binfo[b].niter != wb[b][1].niter else 1e-9, f"rank {r} bootstrap {b}")
+
+
 def test_rccl_entry_points_with_one_rank_communicator():
     """The dlopen'ed RCCL entry points (ncclGetUniqueId / ncclCommInitRank / ncclAllReduce f64 sum on
     the store's stream / ncclCommDestroy) exercised for real with a ONE-rank communicator -- all a
