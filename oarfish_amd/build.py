@@ -71,5 +71,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+MICROBENCH = os.path.join(os.path.dirname(HERE), "scripts", "microbench")
+
+
+def build_microbench(force: bool = False) -> list:
+    """The measurement helpers of scripts/ (stand-alone HIP programs: the FETCH_SIZE calibration
+    stream of scripts/collect_profiles.sh, the atomics / LDS / gather microbenchmarks).  Built in-tree
+    like the library, so they travel to the GPU box; the binaries are git-ignored."""
+    out = []
+    for name in ("stream", "atomics"):
+        src, exe = os.path.join(MICROBENCH, name + ".hip"), os.path.join(MICROBENCH, name)
+        if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+            subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", src, "-o", exe])
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--microbench" in sys.argv:
+        print(build_microbench(force="--force" in sys.argv))
