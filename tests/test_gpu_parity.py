@@ -274,6 +274,38 @@ def test_device_built_layout_equals_host_built_layout(case, monkeypatch):
     assert want[0] > 0
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_device_built_layout_equals_host_built_layout_random_shapes(seed, monkeypatch):
+    """Same equality over randomly shaped stores: read lengths up to 120, 1..300 k transcripts, repeats,
+    empty reads, optional coverage weights, optional per-problem boundaries."""
+    rng = np.random.default_rng(7000 + seed)
+    R = int(rng.choice([1, 9, 700, 20_000, 150_000]))
+    T = int(rng.choice([1, 5, 64, 3_000, 40_000, 300_000]))
+    maxk = int(rng.choice([1, 4, 15, 120]))
+    lens = rng.integers(0, maxk + 1, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    ps = 0
+    if seed % 3 == 2 and T >= 64:                       # per-problem layout: alignments stay inside their problem
+        ps = max(T // int(rng.integers(2, 9)), 1)
+        T = (T // ps) * ps
+        prob = np.repeat(np.sort(rng.integers(0, T // ps, size=R)), lens)
+        tid = (prob * ps + (np.repeat(rng.integers(0, ps, size=R), lens) + rng.integers(0, min(ps, 9), size=nnz)) % ps).astype(np.uint32)
+    else:
+        spread = int(rng.choice([1, 8, 200, max(T, 1)]))
+        tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
+    cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 4 == 0 else None
+    monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
+    want = _layout_hash(rp, tid, p, cov, T, ps)
+    monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")
+    got = _layout_hash(rp, tid, p, cov, T, ps)
+    what = f"seed {seed}: R={R} T={T} maxk={maxk} ps={ps} cov={cov is not None}"
+    assert want[14] == 0 and got[14] == 1, what
+    diff = [f for f, a, b in zip(LAYOUT_FIELDS, got, want) if a != b]
+    assert not diff, f"{what}: differs in {diff} ({got[:4]} vs {want[:4]})"
+
+
 def test_cells_sharded_over_ranks_equal_one_run():
     """Per-cell EM over N GPUs = blocks of cells, no collective: the blocks of 3 ranks (run here one
     after another on the one GPU) concatenate to the single run."""
