@@ -694,6 +694,30 @@ def test_fuzz_random_shapes_match_oracle(seed):
     assert_counts_close(gotb[0], wantb, R, T, RTOL if gbi[0].niter != wbi.niter else 1e-9, what + " (bootstrap)")
 
 
+def test_read_with_more_than_255_window_alignments_takes_the_csr_path():
+    """A read with 300 alignments inside one window cannot be tiled (slice widths are bytes): both layout
+    builders decline, the store runs on the caller-order CSR kernel, and results still match the oracle."""
+    rng = np.random.default_rng(77)
+    T = 2_000
+    lens = np.concatenate([[300], rng.integers(1, 9, size=4_000)])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tid = np.concatenate([np.arange(100, 400), (np.repeat(rng.integers(0, T, size=4_000), lens[1:]) +
+                                                 rng.integers(0, 5, size=int(lens[1:].sum()))) % T]).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 30, size=len(tid)) / 5.0).astype(np.float32)
+    o = c_oracle.Store(rp, tid, p, None, T)
+    want, wi = c_oracle.do_em(o, max_iter=150, conv_thresh=1e-3)
+    with DeviceStore(rp, tid, p, None, T) as d:
+        got, gi = d.em_run(None, 150, 1e-3, 50)
+        import ctypes as C
+        from oarfish_amd import _lib
+        out = (C.c_uint64 * 15)()
+        fn = _lib.lib().oem_debug_layout_hash
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        assert fn(d.handle, C.addressof(out), 15) == _lib.OEM_ERR_STATE       # no tiled layout on this store
+    assert abs(gi.niter - wi.niter) <= 1
+    assert_counts_close(got, want, len(lens), T, RTOL if gi.niter != wi.niter else 1e-9, "CSR path")
+
+
 @pytest.mark.parametrize("tag", ["C", "I", "O"])
 def test_config0_sirv_shaped_store(tag):
     """BASELINE configs[0] on the device: SIRV annotation (69 / 44 / 100 transcripts), bulk mode,
