@@ -261,8 +261,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-                rt[k] = ld_stream<kNT>(&r_tid[o]);
-                rw[k] = ld_stream<kNT>(&r_w[o]);
+                if (!(ablate & 256)) {
+                    rt[k] = ld_stream<kNT>(&r_tid[o]);
+                    rw[k] = ld_stream<kNT>(&r_w[o]);
+                } else { rt[k] = 0; rw[k] = (WT)1; }
                 rrow[k] = ld_stream<kNT>(&r_row[o]);
                 rslot[k] = ld_stream<kNT>(&r_slot[o]);
             }
@@ -274,7 +276,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) { rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0; }
         }
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) rx[k] = theta[(ablate & 128) ? (rt[k] & 7u) : rt[k]] * (double)rw[k];
+        for (int k = 0; k < kRem; ++k) {
+            if (ablate & 256) rx[k] = (tx + k * kTileThreads < td.remote_cnt) ? queue[rslot[k]] : 0.0; // x staged by k_remote_x
+            else rx[k] = theta[(ablate & 128) ? (rt[k] & 7u) : rt[k]] * (double)rw[k];
+        }
     }
     if (!(ablate & 32)) {
         {
@@ -393,6 +398,37 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     }
 }
 
+#ifdef OEM_TILE_ABLATION
+// Timing prototype (ablate bit 256): x = theta * w of the remote alignments computed bucket by bucket
+// with the theta bucket staged in LDS (as the fold kernel stages cnt), written to the queue; the tile
+// kernel then reads x from its queue slots instead of gathering theta from L2.
+__global__ __launch_bounds__(kFoldThreads) void k_remote_x(const uint32_t *__restrict__ bucket_base,
+                                                           double *__restrict__ queue, const uint16_t *__restrict__ q_dst,
+                                                           const float *__restrict__ q_w, const double *__restrict__ theta,
+                                                           uint32_t n_groups, uint32_t n_txps)
+{
+    __shared__ double th[kBucket];
+    const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
+    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
+    const uint64_t span = q1 - q0;
+    const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups), s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
+    if (s0 == s1) return;
+    const uint32_t base = b * kBucket;
+    for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreads) th[i] = base + i < n_txps ? theta[base + i] : 0.0;
+    __syncthreads();
+    uint32_t o = s0 + threadIdx.x;
+    for (; o + 3 * kFoldThreads < s1; o += 4 * kFoldThreads) {
+        uint32_t d[4];
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d[k] = q_dst[o + k * kFoldThreads]; w[k] = q_w[o + k * kFoldThreads]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) queue[o + k * kFoldThreads] = th[d[k]] * (double)w[k];
+    }
+    for (; o < s1; o += kFoldThreads) queue[o] = th[q_dst[o]] * (double)q_w[o];
+}
+#endif
+
 __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restrict__ row_w,
                                                        const uint32_t *__restrict__ perm,
                                                        uint32_t *__restrict__ out, uint64_t n)
@@ -458,6 +494,17 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
         const char *e = getenv("OEM_TILE_VARIANT"); // tuning knob (register blocking of k_em_tile)
         return e ? atoi(e) : 0;
     }();
+#ifdef OEM_TILE_ABLATION
+    {
+        static const uint32_t abl = [] { const char *e = getenv("OEM_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
+        if ((abl & 256) && t.n_remote > 0 && !s->csr.w_is_f64) {
+            uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
+            if (n_groups < 1) n_groups = 1;
+            hipLaunchKernelGGL(k_remote_x, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0, s->stream, t.bucket_base,
+                               t.queue, t.q_dst, (const float *)t.r_w32, theta, n_groups, s->csr.n_txps);
+        }
+    }
+#endif
     if (s->csr.w_is_f64)
         launch_tile_variant<double>(variant, s, (const double *)t.w64, (const double *)t.r_w64, theta,
                                     cnt, state, row_w_perm, problems);
