@@ -17,6 +17,28 @@ from .em import bootstrap, em, em_par
 from .types import EMInfo, InMemoryAlignmentStore, TranscriptInfo
 
 
+def read_short_quant_vec(short_read_path: str, txps_name: Sequence[str]) -> np.ndarray:
+    """`--short-quant` (util/read_function.rs:9-85): a salmon-style `quant.sf` TSV (columns Name, Length,
+    EffectiveLength, TPM, NumReads) projected onto the transcript order of the header -> the EM's
+    `init_abundances` (bulk.rs:118-120).  A name in the file that the header lacks is an error; a
+    header transcript missing from the file gets 0."""
+    import csv
+    with open(short_read_path, newline="") as fh:
+        rdr = csv.DictReader(fh, delimiter="\t")
+        need = {"Name", "Length", "EffectiveLength", "TPM", "NumReads"}
+        if rdr.fieldnames is None or not need.issubset(rdr.fieldnames):
+            raise ValueError(f"{short_read_path}: expected the columns {sorted(need)}")
+        records = {}
+        for rec in rdr:
+            int(rec["Length"]); float(rec["EffectiveLength"]); float(rec["TPM"])   # deserialised (and checked) as in the reference
+            records[rec["Name"]] = float(rec["NumReads"])
+    names = set(txps_name)
+    if not all(k in names for k in records):
+        raise ValueError("There were transcripts in the short read quantification file that didn't appear in "
+                         "the BAM header; cannot proceed.")
+    return np.array([records.get(n, 0.0) for n in txps_name], dtype=np.float64)
+
+
 @dataclass
 class BulkArgs:
     """The `Args` fields this stage reads (prog_opts.rs): defaults are the reference's."""

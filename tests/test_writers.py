@@ -85,3 +85,18 @@ def test_single_cell_matrix_market(tmp_path):
     assert open(out + ".count.mtx").readline() == "%%MatrixMarket matrix coordinate real general\n"
     assert open(out + ".features.txt").read() == "a\nb\nc\nd\n"
     assert open(out + ".barcodes.txt").read() == "AAAC\nAAAG\nAAAT\n"
+
+
+def test_read_short_quant_vec(tmp_path):
+    """read_function.rs:9-85: projection onto the header order, 0 for missing, error for unknown names."""
+    from oarfish_amd.bulk import read_short_quant_vec
+    f = tmp_path / "quant.sf"
+    f.write_text("Name\tLength\tEffectiveLength\tTPM\tNumReads\nt2\t900\t750.5\t12.5\t40.25\nt0\t300\t150\t1\t3\n")
+    v = read_short_quant_vec(str(f), ["t0", "t1", "t2"])
+    assert v.dtype == np.float64 and v.tolist() == [3.0, 0.0, 40.25]
+    with pytest.raises(ValueError, match="didn't appear in the BAM header"):
+        read_short_quant_vec(str(f), ["t0", "t1"])
+    g = tmp_path / "bad.sf"
+    g.write_text("Name\tNumReads\nt0\t3\n")
+    with pytest.raises(ValueError, match="expected the columns"):
+        read_short_quant_vec(str(g), ["t0"])
