@@ -117,7 +117,7 @@ int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uin
 int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass);
 
 /* --------------------------------------------------------------------- */
-/* store builder: the step right before the EM (host side, no GPU needed)  */
+/* store builder: the step right before the EM (host side; only the *_device entry points use the GPU) */
 /* --------------------------------------------------------------------- */
 
 /* AlignmentFilters (src/util/oarfish_types.rs:763-806), the fields filter() reads. */
@@ -164,7 +164,8 @@ void oem_builder_destroy(oem_builder *b);
  * (:955-1130: strand / supplementary / length / 3' / 5' filters, best-score tracking, aligned-
  * fraction test, score threshold, as_prob = expf((score - best) / D) in f32, :1107-1113) followed by
  * add_filtered_group (:718-738).  *out_kept = alignments appended (0: the read was dropped).
- * The coverage intervals add_filtered_group also updates belong to the coverage model (not built). */
+ * The coverage intervals add_filtered_group also updates (:725-728) are recomputed from the retained
+ * alignments by the coverage entry points below. */
 int oem_builder_add_group(oem_builder *b, const oem_aln_record *records, uint32_t n_records,
                           uint32_t *out_kept);
 int oem_builder_dims(const oem_builder *b, uint64_t *n_reads, uint64_t *nnz);
