@@ -67,6 +67,13 @@ def test_fails_loudly_without_a_device():
     emi = oarfish_amd.EMInfo(eq_map=st, txp_info=[oarfish_amd.TranscriptInfo()] * 2)
     with pytest.raises(oarfish_amd.OemError):
         oarfish_amd.em(emi, 1)
+    # the device coverage model likewise: no silent host path behind the *_device entry point
+    tl = np.array([500, 700], dtype=np.uint64)
+    se = np.array([10, 20], dtype=np.uint32), np.array([300, 400], dtype=np.uint32)
+    out = np.zeros(2)
+    rc = _lib.lib().oem_coverage_probs_device(rp.ctypes.data, tid.ctypes.data, se[0].ctypes.data, se[1].ctypes.data,
+                                              tl.ctypes.data, 2, 2, 2, 100, 0, 2.0, 0, out.ctypes.data)
+    assert rc == _lib.OEM_ERR_NO_DEVICE
 
 
 def test_product_never_imports_the_oracle():
