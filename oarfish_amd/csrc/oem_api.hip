@@ -410,9 +410,33 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     return OEM_OK;
 }
 
+// Per-cell batches: cell c's transcripts are relabelled to [c * cell_txps, (c + 1) * cell_txps) -- on
+// the device, after the upload, instead of in a second host copy of the transcript ids.
+struct CellRelabel {
+    const uint64_t *cell_row_off;
+    uint32_t n_cells;
+    uint32_t cell_txps;
+};
+
+__global__ __launch_bounds__(256) void k_relabel_cells(const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ tid,
+                                                       const unsigned long long *__restrict__ cell_row_off,
+                                                       uint32_t n_cells, uint32_t cell_txps, uint64_t n_reads)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    uint32_t a = 0, b = n_cells; // last cell whose first read is <= r
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (cell_row_off[m] <= r) a = m;
+        else b = m;
+    }
+    const uint32_t add = a * cell_txps;
+    for (uint32_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) tid[j] += add;
+}
+
 int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                       const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                      int device, const oem_store_opts *opts, oem_store *s)
+                      int device, const oem_store_opts *opts, oem_store *s, const CellRelabel *relabel = nullptr)
 {
     s->device = device;
     StageTimer tm;
@@ -470,12 +494,42 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
         tm.lap("caller-order CSR upload");
         return OEM_OK;
     }
+    // host copy of the relabelled transcript ids, only for the host builder
+    std::vector<uint32_t> vt;
+    auto host_tids = [&]() -> const uint32_t * {
+        if (!relabel) return tid;
+        if (vt.empty() && nnz) {
+            vt.resize(nnz);
+            for (uint32_t c = 0; c < relabel->n_cells; ++c) {
+                const uint64_t a0 = row_ptr[relabel->cell_row_off[c]], a1 = row_ptr[relabel->cell_row_off[c + 1]];
+                for (uint64_t j = a0; j < a1; ++j) vt[j] = c * relabel->cell_txps + tid[j];
+            }
+        }
+        return vt.data();
+    };
+    auto relabel_on_device = [&]() -> int {
+        if (!relabel || nnz == 0) return OEM_OK;
+        if (m.wide_ptr) return fail(OEM_ERR_ARG, "per-cell batch needs fewer than 2^32 alignments");
+        unsigned long long *d_off = nullptr;
+        OEM_HIP(hipMalloc((void **)&d_off, sizeof(unsigned long long) * ((size_t)relabel->n_cells + 1)));
+        hipError_t e = hipMemcpy(d_off, relabel->cell_row_off, sizeof(unsigned long long) * ((size_t)relabel->n_cells + 1),
+                                 hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_relabel_cells, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s->stream,
+                               (const uint32_t *)m.row_ptr, m.tid, d_off, relabel->n_cells, relabel->cell_txps, n_reads);
+            e = hipStreamSynchronize(s->stream);
+        }
+        hipFree(d_off);
+        if (e != hipSuccess) return fail(OEM_ERR_HIP, "relabelling the cells failed: %s", hipGetErrorString(e));
+        return OEM_OK;
+    };
     // The layout is built on the device from the resident CSR (oem_layout_device.hip); the host
     // builder (oem_layout.cpp, the specification) takes the stores that one does not, or all of them
     // with OEM_LAYOUT_BUILD=host.
     const char *lb = getenv("OEM_LAYOUT_BUILD");
     if (!(lb && lb[0] == 'h')) {
         OEM_TRY(upload_csr());
+        OEM_TRY(relabel_on_device());
         tm.lap("caller-order CSR upload");
         bool built = false;
         OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, &built));
@@ -483,7 +537,7 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
         if (built) return OEM_OK;
         TiledHost h;
         const char *err = nullptr;
-        if (build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
+        if (build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
                                opts ? opts->problem_size : 0u)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
@@ -500,11 +554,12 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
             return;
         }
         csr_rc = upload_csr();
+        if (csr_rc == OEM_OK) csr_rc = relabel_on_device();
         if (csr_rc != OEM_OK) snprintf(csr_err, sizeof(csr_err), "%s", t_err); // t_err is thread-local
     });
     TiledHost h;
     const char *err = nullptr;
-    const bool tiled = build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
+    const bool tiled = build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
                                           opts ? opts->problem_size : 0u);
     tm.lap("tiled layout build (host)");
     up.join();
@@ -812,27 +867,24 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     StageTimer tm;
     const uint64_t total_txps = (uint64_t)n_cells * n_txps;
     if (max_iter < 1 || n_cells < 2 || total_txps >= (1ull << 32) || n_reads >= (1ull << 32)) return OEM_OK;
-    // transcripts of cell p -> [p*T, (p+1)*T)
-    std::vector<uint32_t> vt(nnz);
-    for (uint32_t c = 0; c < n_cells; ++c) {
-        const uint64_t a0 = row_ptr[cell_row_off[c]], a1 = row_ptr[cell_row_off[c + 1]];
-        const uint32_t base = c * n_txps;
-        for (uint64_t j = a0; j < a1; ++j) {
-            if (tid[j] >= n_txps) return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u",
-                                              (unsigned long long)j, tid[j], n_txps);
-            vt[j] = base + tid[j];
-        }
-    }
-    oem_store *s = nullptr;
+    for (uint64_t j = 0; j < nnz; ++j)
+        if (tid[j] >= n_txps)
+            return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u", (unsigned long long)j, tid[j], n_txps);
+    tm.lap("cells: validate");
+    OEM_TRY(ensure_device(device));
+    oem_store *s = new (std::nothrow) oem_store();
+    if (!s) return fail(OEM_ERR_OOM, "oem_em_run_cells: host allocation failed");
     oem_store_opts opts;
     std::memset(&opts, 0, sizeof(opts));
     opts.reorder_rows = 2;
     opts.problem_size = n_txps;
-    tm.lap("cells: virtual transcript ids");
-    int rc = oem_store_create(row_ptr, vt.data(), as_prob, cov_prob, n_reads, nnz, (uint32_t)total_txps, device,
-                              &opts, &s);
-    if (rc != OEM_OK) return rc;
-    std::vector<uint32_t>().swap(vt);
+    // transcripts of cell p -> [p*T, (p+1)*T), relabelled on the device after the upload
+    CellRelabel rl{cell_row_off, n_cells, n_txps};
+    int rc = create_store_impl(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, (uint32_t)total_txps, device, &opts, s, &rl);
+    if (rc != OEM_OK) {
+        free_store(s);
+        return rc;
+    }
     *used = true;
     tm.lap("cells: store create");
 
