@@ -227,23 +227,34 @@ def main():
                          mean_passes=float(np.mean([i.n_passes for i in infos])), mode="one GPU")
         else:
             # replica-parallel: replicates are independent EM runs (em.rs:303-309), so every rank holds
-            # the WHOLE store (1.5 GB of 288 GB) and runs its own replicates -- no collective
-            f_rp, f_tid, f_p, _, _ = make_shard(cfg, 0, 1)
-            with DeviceStore(f_rp, f_tid, f_p, None, cfg["n_txps"], device=local_rank) as full:
-                if args.no_batch_bootstrap:
-                    full.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
-                n_total = args.bootstraps * world
-                full.bootstrap(2, seed=99, max_iter=2)   # untimed: allocates the batch buffers
-                sync()
-                tb = time.perf_counter()
-                _b0, _out, infos = odist.bootstrap_replica_parallel(full, n_total, 1, rank, world)
-                sync()
-                tb = time.perf_counter() - tb
-            tt = torch.tensor([tb], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            boots = dict(value=n_total / float(tt.item()), unit="bootstraps/s", n=n_total,
-                         mean_passes=float(np.mean([i.n_passes for i in infos])),
-                         mode=f"replica-parallel over {world} GPUs, whole store on each, no collective")
+            # the WHOLE store (1.5 GB of 288 GB) and runs its own replicates -- no collective.  This leg is
+            # optional: a rank that fails reports it and the headline line is still printed.
+            n_total = args.bootstraps * world
+            tb, passes, err = float("nan"), [], None
+            try:
+                f_rp, f_tid, f_p, _, _ = make_shard(cfg, 0, 1)
+                with DeviceStore(f_rp, f_tid, f_p, None, cfg["n_txps"], device=local_rank) as full:
+                    if args.no_batch_bootstrap:
+                        full.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
+                    full.bootstrap(2, seed=99, max_iter=2)   # untimed: allocates the batch buffers
+                    torch.cuda.synchronize()
+                    t0b = time.perf_counter()
+                    _b0, _out, infos = odist.bootstrap_replica_parallel(full, n_total, 1, rank, world)
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter() - t0b
+                    passes = [i.n_passes for i in infos]
+            except Exception as e:  # pragma: no cover - only on a broken node
+                err = repr(e)
+            ok = torch.tensor([0.0 if err else 1.0, 0.0 if err else tb], dtype=torch.float64, device="cuda")
+            okmin = ok.clone()
+            dist.all_reduce(okmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ok, op=dist.ReduceOp.MAX)
+            if float(okmin[0].item()) >= 1.0:
+                boots = dict(value=n_total / float(ok[1].item()), unit="bootstraps/s", n=n_total,
+                             mean_passes=float(np.mean(passes)) if passes else None,
+                             mode=f"replica-parallel over {world} GPUs, whole store on each, no collective")
+            else:
+                boots = dict(value=None, error=err or "a rank failed", mode="replica-parallel")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
