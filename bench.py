@@ -134,6 +134,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        # RCCL asks for this with the current HIP runtime ("must be set to avoid performance degradation");
+        # it has to be in the environment before the HIP runtime loads
+        os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
