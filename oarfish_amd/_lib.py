@@ -78,7 +78,8 @@ REC_UNMAPPED, REC_REVERSE, REC_SUPPLEMENTARY, REC_HAS_SCORE = 1, 2, 4, 8
 
 
 class StoreOptsC(C.Structure):
-    _fields_ = [("reorder_rows", C.c_uint32), ("problem_size", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("reorder_rows", C.c_uint32), ("problem_size", C.c_uint32), ("window_cap", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
 
 
 _lib = None

@@ -215,7 +215,7 @@ int ensure_batch(oem_store *s)
 
 bool can_batch(const oem_store *s)
 {
-    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0;
+    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0 && s->tiled.win_cap <= kWin; // batch kernel: narrow windows
 }
 
 // Rolling batch: kBatch slots share every pass over the matrix; a slot whose replicate has finished
@@ -363,6 +363,7 @@ int upload_tiled(oem_store *s, const TiledHost &h)
 {
     DeviceTiled &t = s->tiled;
     t.n_tiles = h.n_tiles;
+    t.win_cap = h.win_cap;
     t.n_buckets = h.n_buckets;
     t.n_rows = h.n_rows;
     t.n_local = h.n_local;
@@ -494,6 +495,11 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
         tm.lap("caller-order CSR upload");
         return OEM_OK;
     }
+    // Window cap of the tiles: sparse stores (few reads per transcript, e.g. per-cell batches) fill
+    // their tiles only with a wide window; dense ones are faster with the narrow one and four copies.
+    uint32_t win_cap = opts ? opts->window_cap : 0u;
+    if (const char *e = getenv("OEM_WIN_CAP")) win_cap = (uint32_t)atoi(e); // tuning knob
+    if (win_cap != kWin && win_cap != kWinWide) win_cap = (n_reads / (n_txps ? n_txps : 1) < 4) ? kWinWide : kWin;
     // host copy of the relabelled transcript ids, only for the host builder
     std::vector<uint32_t> vt;
     auto host_tids = [&]() -> const uint32_t * {
@@ -532,13 +538,13 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
         OEM_TRY(relabel_on_device());
         tm.lap("caller-order CSR upload");
         bool built = false;
-        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, &built));
+        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, win_cap, &built));
         tm.lap("tiled layout build (device)");
         if (built) return OEM_OK;
         TiledHost h;
         const char *err = nullptr;
         if (build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                               opts ? opts->problem_size : 0u)) {
+                               opts ? opts->problem_size : 0u, win_cap)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
             return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
@@ -560,7 +566,7 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     TiledHost h;
     const char *err = nullptr;
     const bool tiled = build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                                          opts ? opts->problem_size : 0u);
+                                          opts ? opts->problem_size : 0u, win_cap);
     tm.lap("tiled layout build (host)");
     up.join();
     tm.lap("wait for the CSR upload");

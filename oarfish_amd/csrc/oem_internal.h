@@ -84,6 +84,7 @@ struct DeviceTiled {
     bool built_on_device = false; // oem_layout_device.hip (else the host builder + upload)
     uint32_t n_tiles = 0;
     uint32_t n_buckets = 0;
+    uint32_t win_cap = kWin; // kWin or kWinWide (sparse stores)
     uint64_t n_rows = 0;    // non-empty reads == length of perm
     uint64_t n_local = 0;
     uint64_t n_remote = 0;
@@ -200,7 +201,7 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 // Tiled E/M pass over the whole store (oem_layout.h): tile kernel + remote-bucket kernel.
 // row_w is in the caller's read order; it is permuted into tile order first.
 // oem_layout_device.hip: the tiled layout built on the device from the resident CSR
-int build_tiled_layout_device(oem_store *s, uint32_t problem_size, bool *built);
+int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built);
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
                          uint32_t problem_size = 0);

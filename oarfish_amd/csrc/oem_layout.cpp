@@ -64,7 +64,7 @@ struct RemoteRec {
 
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err, uint32_t problem_size)
+                        TiledHost *out, const char **err, uint32_t problem_size, uint32_t win_cap)
 {
     (void)nnz;
     if (n_reads >= (1ull << 32)) {
@@ -82,6 +82,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     const uint32_t R = (uint32_t)n_reads;
     const uint32_t n_buckets = (n_txps + kBucket - 1) / kBucket;
     out->n_buckets = n_buckets;
+    out->win_cap = win_cap;
 
     // 1. anchor transcript of every read: the alignment that has the most of the read's
     //    other alignments within +-kMargin transcripts (ties: larger weight, then smaller
@@ -141,7 +142,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             const uint32_t k0 = key[order[pos]];
             uint32_t lo = k0 > kMargin ? k0 - kMargin : 0;
             lo &= ~7u;
-            uint32_t kmax = lo + kWin - kMargin - 1;
+            uint32_t kmax = lo + win_cap - kMargin - 1;
             if (problem_size) { // stay inside the problem of the first read
                 const uint32_t pend = (k0 / problem_size + 1) * problem_size - 1;
                 if (kmax > pend) kmax = pend;
@@ -154,7 +155,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
             // remote record than as a reason to load, clear and flush a whole 2048-entry window.
             const uint32_t kend = key[order[end - 1]];
             uint32_t win = kend - lo + kMargin + 1;
-            if (win > kWin) win = kWin;
+            if (win > win_cap) win = win_cap;
             if (lo + win > n_txps) win = n_txps - lo;
             tile_win.push_back(win);
             pos = end;

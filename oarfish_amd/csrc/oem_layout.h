@@ -39,6 +39,7 @@ namespace oem {
 
 constexpr uint32_t kTileRows = 1024;  // reads per tile (16 slices of 64)
 constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB of LDS); 8*kWin must fit 16 bits
+constexpr uint32_t kWinWide = 2048;   // window cap of sparse stores (few reads per transcript: per-cell batches)
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
 constexpr uint32_t kBucket = 8192;    // transcripts per remote bucket (64 KiB of LDS)
 
@@ -103,6 +104,7 @@ template <typename T> using RawVec = std::vector<T, DefaultInitAlloc<T>>;
 struct TiledHost {
     uint32_t n_tiles = 0;
     uint32_t n_buckets = 0;
+    uint32_t win_cap = kWin; // window cap the tiles were cut for (kWin or kWinWide)
     uint64_t n_rows = 0;    // non-empty reads
     uint64_t n_local = 0;   // local alignments
     uint64_t n_remote = 0;  // remote alignments
@@ -125,9 +127,10 @@ struct TiledHost {
 // Returns false (with `err`) if the store cannot be tiled (n_reads >= 2^32).
 // `problem_size` > 0 declares the transcript space to be the concatenation of independent
 // problems of that many transcripts each (per-cell EM, single_cell.rs:139-160): tiles then
-// never mix reads of two problems.
+// never mix reads of two problems.  `win_cap` (kWin or kWinWide) bounds the LDS window of a tile: sparse
+// stores get more reads per tile from a wider window (the kernels then keep one count-window copy).
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err, uint32_t problem_size = 0);
+                        TiledHost *out, const char **err, uint32_t problem_size = 0, uint32_t win_cap = kWin);
 
 } // namespace oem

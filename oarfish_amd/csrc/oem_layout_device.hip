@@ -68,9 +68,9 @@ __global__ __launch_bounds__(kLThreads) void k_anchor_keys(const uint32_t *__res
 }
 
 // ---- C ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t tile_kmax(uint32_t k0, uint32_t problem_size)
+__device__ __forceinline__ uint32_t tile_kmax(uint32_t k0, uint32_t problem_size, uint32_t win_cap)
 {
-    uint32_t kmax = window_lo(k0) + kWin - kMargin - 1;
+    uint32_t kmax = window_lo(k0) + win_cap - kMargin - 1;
     if (problem_size) {
         const uint32_t pend = (k0 / problem_size + 1) * problem_size - 1;
         if (kmax > pend) kmax = pend;
@@ -79,11 +79,12 @@ __device__ __forceinline__ uint32_t tile_kmax(uint32_t k0, uint32_t problem_size
 }
 
 __global__ __launch_bounds__(kLThreads) void k_next_cut(const uint32_t *__restrict__ skey, uint32_t n_rows,
-                                                        uint32_t problem_size, uint32_t *__restrict__ next)
+                                                        uint32_t problem_size, uint32_t win_cap,
+                                                        uint32_t *__restrict__ next)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
-    const uint32_t kmax = tile_kmax(skey[i], problem_size);
+    const uint32_t kmax = tile_kmax(skey[i], problem_size, win_cap);
     uint32_t lim = i + kTileRows;
     if (lim > n_rows) lim = n_rows;
     // first index in (i, lim) whose key exceeds kmax, else lim
@@ -135,8 +136,8 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long *a, uint32_t
 __global__ __launch_bounds__(kLThreads) void k_tile_pass1(
     const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tid, const uint32_t *__restrict__ skey,
     const uint32_t *__restrict__ order, const uint32_t *__restrict__ tile_start, uint32_t n_txps,
-    uint32_t n_buckets, uint32_t problem_size, TileDesc *__restrict__ tiles, TileAux *__restrict__ aux,
-    uint32_t *__restrict__ perm, uint32_t *__restrict__ cnt_tb, uint32_t *too_wide)
+    uint32_t n_buckets, uint32_t problem_size, uint32_t win_cap, TileDesc *__restrict__ tiles,
+    TileAux *__restrict__ aux, uint32_t *__restrict__ perm, uint32_t *__restrict__ cnt_tb, uint32_t *too_wide)
 {
     __shared__ unsigned long long sk[kTileRows];
     __shared__ uint32_t nloc_s[kTileRows];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kLThreads) void k_tile_pass1(
     const uint32_t p0 = tile_start[ti], p1 = tile_start[ti + 1], n = p1 - p0;
     const uint32_t k0 = skey[p0], lo = window_lo(k0);
     uint32_t win = skey[p1 - 1] - lo + kMargin + 1;
-    if (win > kWin) win = kWin;
+    if (win > win_cap) win = win_cap;
     if (lo + win > n_txps) win = n_txps - lo;
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
     __syncthreads();
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kLThreads) void k_tile_pass1(
             const uint32_t nl = nloc > 255u ? 255u : nloc;
             nloc_s[i] = nl;
             // sort 1: local count descending, anchor ascending, arrival order
-            sk[i] = ((unsigned long long)(255u - nl) << 19) | ((unsigned long long)(skey[p0 + i] - lo) << 10) | i;
+            sk[i] = ((unsigned long long)(255u - nl) << 21) | ((unsigned long long)(skey[p0 + i] - lo) << 10) | i; // anchor - lo < kWinWide: 11 bits
         } else {
             sk[i] = ~0ull;
         }
@@ -194,9 +195,9 @@ __global__ __launch_bounds__(kLThreads) void k_tile_pass1(
         uint32_t c = 0;
         for (uint32_t q = threadIdx.x; q < n; q += blockDim.x, ++c) {
             const unsigned long long k1 = sk[q];
-            const uint32_t idx = (uint32_t)(k1 & 1023u), anc = (uint32_t)(k1 >> 10) & 511u;
-            const uint32_t inv_nl = (uint32_t)(k1 >> 19);
-            v[c] = ((unsigned long long)inv_nl << 29) | ((unsigned long long)(q - head[q]) << 19) |
+            const uint32_t idx = (uint32_t)(k1 & 1023u), anc = (uint32_t)(k1 >> 10) & 2047u;
+            const uint32_t inv_nl = (uint32_t)(k1 >> 21);
+            v[c] = ((unsigned long long)inv_nl << 31) | ((unsigned long long)(q - head[q]) << 21) |
                    ((unsigned long long)anc << 10) | idx;
         }
         __syncthreads();
@@ -454,7 +455,7 @@ int out_alloc(T **p, size_t n, uint64_t *acct)
 }
 
 template <typename WT>
-int build_impl(oem_store *s, uint32_t problem_size, const WT *w_in, WT **w_out, WT **r_w_out, bool *built)
+int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, const WT *w_in, WT **w_out, WT **r_w_out, bool *built)
 {
     *built = false;
     const DeviceCsr &m = s->csr;
@@ -493,7 +494,7 @@ int build_impl(oem_store *s, uint32_t problem_size, const WT *w_in, WT **w_out, 
     // C
     uint32_t *next = iota; // reuse
     hipLaunchKernelGGL(k_next_cut, dim3((n_rows + kLThreads - 1) / kLThreads), dim3(kLThreads), 0, st, skey, n_rows,
-                       problem_size, next);
+                       problem_size, win_cap, next);
     OEM_HIP(hipGetLastError());
     uint32_t *tile_start;
     const uint32_t cap = n_rows + 1; // every tile holds at least one read
@@ -514,7 +515,7 @@ int build_impl(oem_store *s, uint32_t problem_size, const WT *w_in, WT **w_out, 
     OEM_TRY(out_alloc(&t.tiles, n_tiles, &s->hbm_bytes));
     OEM_TRY(out_alloc(&t.perm, n_rows, &s->hbm_bytes));
     hipLaunchKernelGGL(k_tile_pass1, dim3(n_tiles), dim3(kLThreads), 0, st, row_ptr, m.tid, skey, order, tile_start, T,
-                       n_buckets, problem_size, t.tiles, aux, t.perm, cnt_tb, d_small + 2);
+                       n_buckets, problem_size, win_cap, t.tiles, aux, t.perm, cnt_tb, d_small + 2);
     OEM_HIP(hipGetLastError());
 
     // E
@@ -581,6 +582,7 @@ int build_impl(oem_store *s, uint32_t problem_size, const WT *w_in, WT **w_out, 
     OEM_TRY(out_alloc(&t.queue, n_remote, &s->hbm_bytes));
     OEM_TRY(out_alloc(&t.row_w_perm, n_rows, &s->hbm_bytes));
     t.n_tiles = n_tiles;
+    t.win_cap = win_cap;
     t.n_buckets = n_buckets;
     t.n_remote = n_remote;
     t.n_local = m.nnz - n_remote;
@@ -594,14 +596,14 @@ int build_impl(oem_store *s, uint32_t problem_size, const WT *w_in, WT **w_out, 
 
 // Builds s->tiled from s->csr on the device.  *built = false (and nothing allocated that matters)
 // when this builder does not take the store; the caller then uses the host builder.
-int build_tiled_layout_device(oem_store *s, uint32_t problem_size, bool *built)
+int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built)
 {
     *built = false;
     const DeviceCsr &m = s->csr;
     if (m.wide_ptr || m.n_reads == 0 || m.n_reads >= (1ull << 31) || m.nnz >= (1ull << 32)) return OEM_OK;
     int rc;
-    if (m.w_is_f64) rc = build_impl<double>(s, problem_size, m.w64, &s->tiled.w64, &s->tiled.r_w64, built);
-    else rc = build_impl<float>(s, problem_size, m.w32, &s->tiled.w32, &s->tiled.r_w32, built);
+    if (m.w_is_f64) rc = build_impl<double>(s, problem_size, win_cap, m.w64, &s->tiled.w64, &s->tiled.r_w64, built);
+    else rc = build_impl<float>(s, problem_size, win_cap, m.w32, &s->tiled.w32, &s->tiled.r_w32, built);
     if (rc != OEM_OK || !*built) { // leave no half-built layout behind
         DeviceTiled &t = s->tiled;
         hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32); hipFree(t.w64); hipFree(t.r_tid);

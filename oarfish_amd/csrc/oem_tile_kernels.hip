@@ -192,7 +192,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 }
 
 template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kUpfront, int kSched,
-          bool kNT>
+          bool kNT, uint32_t kWinT = kWin>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #endif
     if (state && state->done) return;
 
-    __shared__ double theta_l[kWin];
-    __shared__ double cnt_l[kWin * kCopies];
+    __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
+    __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
     if (!(ablate & 32)) {
         {
-            constexpr uint32_t kPer = (kWin + kTileThreads - 1) / kTileThreads;
+            constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
             double tw[kPer];
 #pragma unroll
             for (uint32_t u = 0; u < kPer; ++u) {
@@ -474,6 +474,19 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
         if (nt) OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, true);                                    \
         else OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, false);                                      \
     } while (0)
+    if (t.win_cap > kWin) {
+        // sparse store (window cap kWinWide): one count-window copy keeps the LDS at 40 KiB; same-address
+        // atomics are rare when few reads share a transcript (per-cell EM loop -16 % against 512 x 4)
+        if (nt)
+            hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, false, 5, true, kWinWide>), dim3(t.n_tiles), dim3(256),
+                               pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue,
+                               theta, cnt, state, row_w_perm, ablate, problems);
+        else
+            hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, false, 5, false, kWinWide>), dim3(t.n_tiles), dim3(256),
+                               pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue,
+                               theta, cnt, state, row_w_perm, ablate, problems);
+        return;
+    }
     switch (variant) {
     case 1: OEM_TILE(8, 3, 512, 2, 4, true, 4); break;   // all slices up front, 8 waves
     case 2: OEM_TILE(12, 6, 256, 2, 4, false, 4); break;

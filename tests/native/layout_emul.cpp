@@ -16,7 +16,10 @@ extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, 
 {
     TiledHost h;
     const char *err = nullptr;
-    if (!build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err, problem_size)) return 1;
+    const char *wc = getenv("LAYOUT_EMUL_WIN_CAP"); // tests pick the window cap (kWin or kWinWide)
+    if (!build_tiled_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err, problem_size,
+                            wc ? (uint32_t)atoi(wc) : kWin))
+        return 1;
     if (problem_size) // a tile never mixes reads of two problems
         for (uint32_t ti = 0; ti < h.n_tiles; ++ti) {
             const TileDesc &td = h.tiles[ti];
@@ -38,8 +41,8 @@ extern "C" int layout_emul_m_step(const uint64_t *row_ptr, const uint32_t *tid, 
     }
     for (uint32_t ti = 0; ti < h.n_tiles; ++ti) {
         const TileDesc &td = h.tiles[ti];
-        if (td.win_len > kWin || td.n_rows > kTileRows || td.n_slices * 64 < td.n_rows) return 4;
-        std::vector<double> theta_l(kWin, 0.0 / 0.0), cnt_l(kWin, 0.0), den_l(kTileRows, 0.0);
+        if (td.win_len > h.win_cap || h.win_cap > kWinWide || td.n_rows > kTileRows || td.n_slices * 64 < td.n_rows) return 4;
+        std::vector<double> theta_l(kWinWide, 0.0 / 0.0), cnt_l(kWinWide, 0.0), den_l(kTileRows, 0.0);
         for (uint32_t i = 0; i < td.win_len; ++i) { theta_l[i] = theta[td.lo + i]; }
         for (uint32_t i = 0; i < td.remote_cnt; ++i) {
             const uint32_t o = td.remote_begin + i;

@@ -233,8 +233,9 @@ LAYOUT_FIELDS = ["n_tiles", "n_rows", "n_local", "n_remote", "tiles", "perm", "c
                  "r_slot", "q_dst", "bucket_base"]
 
 
+@pytest.mark.parametrize("win_cap", ["512", "2048"])
 @pytest.mark.parametrize("case", ["medium", "coverage", "sparse_wide", "tiny", "empty_rows_dups", "cells", "c2"])
-def test_device_built_layout_equals_host_built_layout(case, monkeypatch):
+def test_device_built_layout_equals_host_built_layout(case, win_cap, monkeypatch):
     """oem_layout_device.hip against its specification (oem_layout.cpp): every array of the tiled layout,
     element for element (64-bit hashes of the resident arrays), over dense / sparse / ragged stores, the
     f64 coverage weights and the per-cell problem boundaries."""
@@ -264,6 +265,7 @@ def test_device_built_layout_equals_host_built_layout(case, monkeypatch):
         ps, T = T, 9 * T
     else:
         st = synth.make_store(1_000_000, 60_000, seed=synth.BASE_SEED); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    monkeypatch.setenv("OEM_WIN_CAP", win_cap)
     monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
     want = _layout_hash(rp, tid, p, cov, T, ps)
     monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")
@@ -296,6 +298,8 @@ def test_device_built_layout_equals_host_built_layout_random_shapes(seed, monkey
         tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
     p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
     cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 4 == 0 else None
+    if seed % 2:
+        monkeypatch.setenv("OEM_WIN_CAP", "2048" if seed % 4 == 1 else "512")   # else: chosen from the density
     monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
     want = _layout_hash(rp, tid, p, cov, T, ps)
     monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")

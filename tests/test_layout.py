@@ -70,6 +70,34 @@ def test_layout_large_window_overflow(emul, coverage):
     assert w_slots < 1.15 * n_local           # SELL padding stays small
 
 
+@pytest.mark.parametrize("what", ["sparse", "dense", "cells"])
+def test_layout_wide_window(emul, monkeypatch, what):
+    """Window cap kWinWide (2048 transcripts, chosen for sparse stores such as per-cell batches): same
+    results, and on a sparse store many more reads per tile than with the narrow window."""
+    ps = 0
+    if what == "sparse":
+        st = synth.make_store(40_000, 50_000, seed=23, threads=2)       # 0.8 reads per transcript
+        rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    elif what == "dense":
+        st = synth.make_store(60_000, 2_500, seed=24, threads=2)
+        rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
+    else:
+        n_cells, Tc = 4, 3_000
+        cell_off, rp, tid, p = synth.make_cells(n_cells, 2_500, Tc, seed=25)
+        cell_of_row = np.repeat(np.arange(n_cells), np.diff(cell_off.astype(np.int64)))
+        tid = (tid.astype(np.int64) + np.repeat(cell_of_row, np.diff(rp.astype(np.int64))) * Tc).astype(np.uint32)
+        T, ps = n_cells * Tc, Tc
+    theta = np.random.default_rng(8).lognormal(0, 1.5, size=T)
+    want = c_oracle.m_step(c_oracle.Store(rp, tid, p, None, T), theta)
+    narrow, s_n = _run(emul, rp, tid, p, None, T, theta, problem_size=ps)
+    monkeypatch.setenv("LAYOUT_EMUL_WIN_CAP", "2048")
+    wide, s_w = _run(emul, rp, tid, p, None, T, theta, problem_size=ps)
+    np.testing.assert_allclose(narrow, want, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(wide, want, rtol=1e-10, atol=1e-10)
+    if what != "dense":
+        assert int(s_w[0]) < 0.6 * int(s_n[0])      # fewer, fuller tiles
+
+
 def test_layout_empty_rows_and_sparse_keys(emul):
     # empty reads are skipped; primaries far apart force many narrow tiles
     rp = np.array([0, 0, 2, 2, 3, 5, 5], dtype=np.uint64)
