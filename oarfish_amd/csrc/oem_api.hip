@@ -1049,7 +1049,10 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
             const uint64_t reads = cell_row_off[c1 + 1] - cell_row_off[c0];
             const uint64_t gnnz = row_ptr[cell_row_off[c1 + 1]] - row_ptr[cell_row_off[c0]];
             const uint64_t buckets = (cells * n_txps + kBucket - 1) / kBucket;
-            const uint64_t tiles_est = reads / 256 + 2 * cells;
+            // tiles per group: ~300 reads per tile with the narrow window cap on sparse cells, ~700 with the
+            // wide one that create_store_impl picks below 4 reads per transcript
+            const bool wide = reads / (cells * n_txps) < 4;
+            const uint64_t tiles_est = reads / (wide ? 600 : 256) + 2 * cells;
             if (cells * n_txps >= (1ull << 32) || reads >= (1ull << 32) || gnnz > max_group_nnz ||
                 tiles_est * buckets > (1ull << 28))
                 break;
