@@ -922,13 +922,21 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             if ((rc2 = launch_multi_init(s, s->theta, d_reads, mb)) != OEM_OK) break;
             EmParams p{n_txps, max_iter, 50u /* em::em, single_cell.rs:150 */, conv_thresh};
             const uint32_t total = max_iter + 1;
+            // one workgroup per bucket folds the queue AND finishes the pass (A/B knob: OEM_CELLS_FUSED_FOLD=0)
+            const char *ff = getenv("OEM_CELLS_FUSED_FOLD");
+            const bool fused_fold = !(ff && ff[0] == '0');
             uint32_t launched = 0, unfinished = n_cells;
             while (launched < total && unfinished) {
                 uint32_t chunk = launched == 0 ? 53 : 16;
                 if (chunk > total - launched) chunk = total - launched;
                 for (uint32_t k = 0; k < chunk && rc2 == OEM_OK; ++k) {
-                    rc2 = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, mb.state, n_txps);
-                    if (rc2 == OEM_OK) rc2 = launch_multi_reldiff(s, s->theta, s->cnt, mb, p);
+                    if (fused_fold) {
+                        rc2 = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, mb.state, n_txps, true);
+                        if (rc2 == OEM_OK) rc2 = launch_multi_fold_reldiff(s, s->theta, s->cnt, mb, p);
+                    } else {
+                        rc2 = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, mb.state, n_txps);
+                        if (rc2 == OEM_OK) rc2 = launch_multi_reldiff(s, s->theta, s->cnt, mb, p);
+                    }
                 }
                 if (rc2 != OEM_OK) break;
                 launched += chunk;

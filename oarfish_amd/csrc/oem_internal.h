@@ -204,9 +204,10 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built);
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
-                         uint32_t problem_size = 0);
+                         uint32_t problem_size = 0, bool skip_fold = false);
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
+int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int launch_multi_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_perm);
 

@@ -51,6 +51,71 @@ __global__ __launch_bounds__(kMT) void k_multi_reldiff(double *__restrict__ thet
         atomicMax(&st[p].rel_bits, (unsigned long long)__double_as_longlong(rel));
 }
 
+
+// The fold kernel of a per-cell batch finishes the pass itself.  A cell's remote alignments spread over a
+// handful of buckets with few entries each, so every bucket is owned by ONE workgroup: once the bucket's
+// queue range is summed in LDS, counts = (what the tile kernels flushed into cnt) + (the LDS sums) are
+// complete for these transcripts, and rel-diff / swap / clear (em.rs:194-207) or the parking of a FINAL
+// cell's counts (em.rs:254) happen right here -- no flush atomics, no second sweep over theta and cnt.
+constexpr int kFT = 1024;
+constexpr uint32_t kMaxCellsPerBucket = 64; // beyond that (T < ~130) the per-cell maxima go straight to global atomics
+
+__global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__restrict__ bucket_base,
+                                                            const double *__restrict__ queue,
+                                                            const uint16_t *__restrict__ q_dst, double *__restrict__ theta,
+                                                            double *__restrict__ cnt, double *__restrict__ out,
+                                                            BatchState *st, uint32_t n_txps, uint32_t T)
+{
+    __shared__ double acc[kBucket];
+    __shared__ unsigned long long cmax[kMaxCellsPerBucket];
+    __shared__ uint32_t phase_l[kMaxCellsPerBucket];
+    const uint32_t b = blockIdx.x;
+    const uint32_t t0 = b * kBucket;
+    uint32_t t1 = t0 + kBucket - 1;
+    if (t1 >= n_txps) t1 = n_txps - 1;
+    const uint32_t p0 = t0 / T, p1 = t1 / T, n_cells = p1 - p0 + 1;
+    const bool small = n_cells <= kMaxCellsPerBucket;
+    bool live = false;
+    for (uint32_t p = p0; p <= p1; ++p) live = live || st[p].phase != kPhaseFinished;
+    if (!live) return;
+    if (small && threadIdx.x < n_cells) {
+        cmax[threadIdx.x] = 0ull;
+        phase_l[threadIdx.x] = st[p0 + threadIdx.x].phase;
+    }
+    for (uint32_t i = threadIdx.x; i < kBucket; i += kFT) acc[i] = 0.0;
+    __syncthreads();
+    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
+    for (uint32_t o = q0 + threadIdx.x; o < q1; o += kFT) {
+        const double v = queue[o];
+        if (v != 0.0) __hip_atomic_fetch_add(&acc[q_dst[o]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kBucket && t0 + i < n_txps; i += kFT) {
+        const uint32_t t = t0 + i, p = t / T;
+        const uint32_t phase = small ? phase_l[p - p0] : st[p].phase;
+        if (phase == kPhaseFinished) continue;
+        const double cc = cnt[t] + acc[i];
+        cnt[t] = 0.0;                                             // em.rs:207
+        if (phase == kPhaseFinal) {
+            out[t] = cc;                                          // em.rs:254
+        } else {
+            const double pc = theta[t];
+            theta[t] = cc;                                        // em.rs:204
+            if (pc > OEM_MIN_READ_THRESH) {                       // em.rs:195-199 (signed, floored at 0 by the max)
+                const double rel = (cc - pc) / pc;
+                if (rel > 0.0) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(rel);
+                    if (small) atomicMax(&cmax[p - p0], bits);
+                    else atomicMax(&st[p].rel_bits, bits);
+                }
+            }
+        }
+    }
+    if (!small) return;
+    __syncthreads();
+    if (threadIdx.x < n_cells && cmax[threadIdx.x] != 0ull) atomicMax(&st[p0 + threadIdx.x].rel_bits, cmax[threadIdx.x]);
+}
+
 // one thread per cell: the stopping rule (em.rs:212-218, :181)
 __global__ __launch_bounds__(kMT) void k_multi_decide(BatchState *st, uint32_t n_problems, EmParams p,
                                                       uint32_t *n_unfinished)
@@ -104,6 +169,23 @@ int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_rea
     uint32_t gx = (T + kMT - 1) / kMT;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_multi_init, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, d_problem_reads, T);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+// fold + rel-diff in one kernel (see k_multi_fold_reldiff), then the per-cell state machine
+int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p)
+{
+    const DeviceTiled &t = s->tiled;
+    const uint32_t T = mb.problem_size;
+    uint32_t gx = (T + kMT - 1) / kMT;
+    if (gx > 64) gx = 64;
+    const uint32_t gp = (mb.n_problems + kMT - 1) / kMT;
+    hipLaunchKernelGGL(k_multi_fold_reldiff, dim3(t.n_buckets), dim3(kFT), 0, s->stream, t.bucket_base, t.queue, t.q_dst,
+                       theta, cnt, mb.out, mb.state, s->csr.n_txps, T);
+    hipLaunchKernelGGL(k_multi_decide, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems, p, mb.n_unfinished);
+    hipLaunchKernelGGL(k_multi_zero_small, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, mb.state, T);
+    hipLaunchKernelGGL(k_multi_mark_zeroed, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

@@ -499,7 +499,7 @@ static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT
 }
 
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
-                         const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size)
+                         const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
@@ -525,7 +525,7 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
         launch_tile_variant<float>(variant, s, (const float *)t.w32, (const float *)t.r_w32, theta, cnt,
                                    state, row_w_perm, problems);
     OEM_HIP(hipGetLastError());
-    if (t.n_remote > 0) {
+    if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
         // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
         // fewer, longer-running workgroups mean fewer flush atomics)
         static const uint32_t fold_wgs = [] {
