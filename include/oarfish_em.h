@@ -69,8 +69,8 @@ typedef struct {
     uint32_t problem_size; /* 0 = one EM problem; > 0: the transcript space is the concatenation of
                               independent problems of this many transcripts (tiles never mix them);
                               set by oem_em_run_cells for its per-cell batches */
-    uint32_t window_cap;   /* transcripts per tile window: 0 = chosen from the store's density (fewer than 4
-                              reads per transcript: 2048, else 512), or 512 / 2048 to force it */
+    uint32_t window_cap;   /* transcripts per tile window: 0 = chosen from the store (large and sparse -- at least
+                              1 M reads, fewer than 2 per transcript: 2048; else 512), or 512 / 2048 to force it */
     uint32_t reserved[5];
 } oem_store_opts;
 

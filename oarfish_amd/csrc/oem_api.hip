@@ -499,7 +499,13 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     // their tiles only with a wide window; dense ones are faster with the narrow one and four copies.
     uint32_t win_cap = opts ? opts->window_cap : 0u;
     if (const char *e = getenv("OEM_WIN_CAP")) win_cap = (uint32_t)atoi(e); // tuning knob
-    if (win_cap != kWin && win_cap != kWinWide) win_cap = (n_reads / (n_txps ? n_txps : 1) < 4) ? kWinWide : kWin;
+    if (win_cap != kWin && win_cap != kWinWide) {
+        // measured (scripts/wincap_ab.py): the wide cap wins on large sparse stores (2 M reads over 4 M
+        // transcripts -10 %, a 625-cell batch -16 %), the narrow one on dense stores and on small ones,
+        // which are latency-bound either way
+        const bool sparse = n_reads < 2 * (uint64_t)(n_txps ? n_txps : 1);
+        win_cap = (sparse && n_reads >= 1000000) ? kWinWide : kWin;
+    }
     // host copy of the relabelled transcript ids, only for the host builder
     std::vector<uint32_t> vt;
     auto host_tids = [&]() -> const uint32_t * {
@@ -1059,7 +1065,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
             const uint64_t buckets = (cells * n_txps + kBucket - 1) / kBucket;
             // tiles per group: ~300 reads per tile with the narrow window cap on sparse cells, ~700 with the
             // wide one that create_store_impl picks below 4 reads per transcript
-            const bool wide = reads / (cells * n_txps) < 4;
+            const bool wide = reads < 2 * cells * n_txps && reads >= 1000000; // as create_store_impl chooses
             const uint64_t tiles_est = reads / (wide ? 600 : 256) + 2 * cells;
             if (cells * n_txps >= (1ull << 32) || reads >= (1ull << 32) || gnnz > max_group_nnz ||
                 tiles_est * buckets > (1ull << 28))
