@@ -71,7 +71,10 @@ typedef struct {
                               set by oem_em_run_cells for its per-cell batches */
     uint32_t window_cap;   /* transcripts per tile window: 0 = chosen from the store (large and sparse -- at least
                               1 M reads, fewer than 2 per transcript: 2048; else 512), or 512 / 2048 to force it */
-    uint32_t reserved[5];
+    uint32_t layout_build; /* 0 = build the tiled layout on the device (the host builder takes the stores the
+                              device builder declines); 1 = always the host builder (oem_layout.cpp, the
+                              specification the device builder is tested against) */
+    uint32_t reserved[4];
 } oem_store_opts;
 
 /* --------------------------------------------------------------------- */

@@ -79,27 +79,26 @@ REC_UNMAPPED, REC_REVERSE, REC_SUPPLEMENTARY, REC_HAS_SCORE = 1, 2, 4, 8
 
 class StoreOptsC(C.Structure):
     _fields_ = [("reorder_rows", C.c_uint32), ("problem_size", C.c_uint32), ("window_cap", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("layout_build", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
-_lib = None
+_lib = None       # the library the package calls into (the product, unless inside `testing()`)
+_product = None
+_testing = None
+TESTING_LIB_PATH = os.path.join(HERE, "liboarfish_em_testing.so")
 
 
-def lib() -> C.CDLL:
-    """Load the library (once).  Raises if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _load(path: str) -> C.CDLL:
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m oarfish_amd.build` "
+            f"{path} is missing: build it with `python -m oarfish_amd.build` "
             "(or __graft_entry__.build()).  oarfish_amd has no CPU fallback."
         )
     try:  # make sure the process has ONE HIP runtime / RCCL: torch's, if torch is around
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C ABI
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, u64, u32, i32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
     L.oem_abi_version.restype = i32
     L.oem_last_error.restype = C.c_char_p
@@ -137,11 +136,49 @@ def lib() -> C.CDLL:
     L.oem_time_m_step.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_time_em_iters.argtypes = [vp, u32, C.POINTER(C.c_float)]
     for name in ABI_SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("oem_abi_version",):
-            pass
-    _lib = L
+        getattr(L, name)
     return L
+
+
+def lib() -> C.CDLL:
+    """The library in use: the product (liboarfish_em.so), loaded once; raises if it has not been
+    built.  Inside `with testing():` it is the test-only build instead."""
+    global _lib, _product
+    if _lib is None:
+        if _product is None:
+            _product = _load(LIB_PATH)
+        _lib = _product
+    return _lib
+
+
+def testing_lib() -> C.CDLL:
+    """liboarfish_em_testing.so: the product objects plus the hooks of csrc/oem_testing.hip and the
+    environment-driven knobs (-DOEM_TESTING).  Only tests/ and scripts/ load it."""
+    global _testing
+    if _testing is None:
+        L = _load(TESTING_LIB_PATH)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        L.oem_debug_layout_hash.argtypes = [vp, vp, u32]
+        L.oem_debug_local_comm_create.argtypes = [i32, i32, vp]
+        L.oem_test_reldiff_stress.argtypes = [u32, u32, u32, i32, vp]
+        _testing = L
+    return _testing
+
+
+class testing:
+    """Context manager: every call of the package goes to the test-only library inside the block
+    (handles created inside must be closed inside: the two libraries do not share state)."""
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self._prev = _lib
+        _lib = testing_lib()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
 
 
 def check(rc: int) -> None:

@@ -1,7 +1,12 @@
-"""Builds liboarfish_em.so (the C-ABI library) in-tree with hipcc for gfx950.
+"""Builds the C-ABI libraries in-tree with hipcc for gfx950.
 
-The library is plain HIP/C++: no torch types, no pybind.  hipcc cross-compiles
-gfx950 code objects without a GPU, so this runs in the CPU-only container too.
+  liboarfish_em.so          the product: include/oarfish_em.h and nothing else
+  liboarfish_em_testing.so  the same objects plus the test hooks of csrc/oem_testing.hip and the
+                            env-driven knobs (-DOEM_TESTING); loaded only by tests/ and scripts/
+
+Plain HIP/C++: no torch types, no pybind.  hipcc cross-compiles gfx950 code objects without a GPU,
+so this runs in the CPU-only container too.  Every source is compiled to its own object (in
+parallel, cached by mtime under csrc/_obj/) and the two libraries are linked from them.
 """
 from __future__ import annotations
 
@@ -13,13 +18,22 @@ if __name__ == "__main__" and sys.path and os.path.abspath(sys.path[0]) == os.pa
 
 import shutil      # noqa: E402
 import subprocess  # noqa: E402
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(HERE, "liboarfish_em.so")
+TESTING_LIB_PATH = os.path.join(HERE, "liboarfish_em_testing.so")
 
-SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_coverage_device.hip", "oem_builder.cpp", "oem_comm.cpp"]
+# sources of the product library
+SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip",
+           "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_coverage_device.hip",
+           "oem_builder.cpp", "oem_comm.cpp", "oem_knobs.cpp"]
+# the testing library swaps these for their -DOEM_TESTING build and adds the hooks
+TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp"]
+TESTING_ONLY = ["oem_testing.hip"]
 HEADERS = ["oem_internal.h", "oem_layout.h", os.path.join(INCLUDE, "oarfish_em.h")]
 
 FLAGS = [
@@ -27,7 +41,6 @@ FLAGS = [
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     "-munsafe-fp-atomics",  # hardware global_atomic_add_f64 / ds_add_f64, no CAS loops
     "-ffp-contract=off",    # keep (theta*w)*inv as written; parity is judged in f64
     "-Wall",
@@ -44,30 +57,71 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found; cannot build liboarfish_em.so")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _header_paths():
+    return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def _obj_path(src: str, testing: bool) -> str:
+    return os.path.join(OBJ, os.path.splitext(src)[0] + (".testing.o" if testing else ".o"))
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
-        h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS
-    ] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip"]
-    if os.environ.get("OEM_TILE_ABLATION"):  # profiling builds only: enables the OEM_TILE_ABLATE switches
-        cmd.append("-DOEM_TILE_ABLATION")
-        if os.environ.get("OEM_ABL_BYTEW"):
-            cmd.append("-DOEM_ABL_BYTEW")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp", "-ldl"]
+def _jobs():
+    """(source, testing?) of every object the two libraries are linked from."""
+    jobs = [(s, False) for s in SOURCES]
+    jobs += [(s, True) for s in TESTING_VARIANTS + TESTING_ONLY]
+    return jobs
+
+
+def needs_build() -> bool:
+    hdr = _header_paths()
+    objs = [_obj_path(s, t) for s, t in _jobs()]
+    if any(_stale(_obj_path(s, t), [os.path.join(CSRC, s)] + hdr) for s, t in _jobs()):
+        return True
+    return _stale(LIB_PATH, objs) or _stale(TESTING_LIB_PATH, objs)
+
+
+def _compile(src: str, testing: bool, verbose: bool) -> None:
+    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src)]
+    if testing:
+        cmd.append("-DOEM_TESTING")
+    out = _obj_path(src, testing)
+    cmd += ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(out + ".tmp", out)
+
+
+def _link(objs, out: str, verbose: bool) -> None:
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", out + ".tmp", "-ldl", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what is stale and link both libraries; returns the product library's path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _header_paths()
+    todo = [(s, t) for s, t in _jobs()
+            if force or _stale(_obj_path(s, t), [os.path.join(CSRC, s)] + hdr)]
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda j: _compile(j[0], j[1], verbose), todo))
+    product = [_obj_path(s, False) for s in SOURCES]
+    testing = [_obj_path(s, s in TESTING_VARIANTS) for s in SOURCES] + [_obj_path(s, True) for s in TESTING_ONLY]
+    _link(product, LIB_PATH, verbose)
+    _link(testing, TESTING_LIB_PATH, verbose)
     return LIB_PATH
 
 

@@ -75,21 +75,42 @@ int dev_alloc(T **p, size_t n, uint64_t *acct)
     return OEM_OK;
 }
 
+// Range checks of the caller's CSR, split over a few host threads (80 M alignments: 18 ms serial, the
+// same order as the device layout build).  Reports the first offending index.
 int validate_csr(const uint64_t *row_ptr, const uint32_t *tid, uint64_t n_reads, uint64_t nnz,
                  uint32_t n_txps)
 {
     if (row_ptr[0] != 0) return fail(OEM_ERR_ARG, "row_ptr[0] must be 0 (oarfish_types.rs:645)");
-    for (uint64_t i = 0; i < n_reads; ++i)
-        if (row_ptr[i + 1] < row_ptr[i])
-            return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu",
-                        (unsigned long long)i);
+    constexpr uint64_t kNone = ~0ull;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1 || n_reads + nnz < (1u << 20)) nt = 1;
+    std::vector<uint64_t> bad_row(nt, kNone), bad_tid(nt, kNone);
+    auto scan = [&](unsigned k) {
+        const uint64_t r0 = n_reads * k / nt, r1 = n_reads * (k + 1) / nt;
+        for (uint64_t i = r0; i < r1; ++i)
+            if (row_ptr[i + 1] < row_ptr[i]) { bad_row[k] = i; break; }
+        const uint64_t a0 = nnz * k / nt, a1 = nnz * (k + 1) / nt;
+        for (uint64_t j = a0; j < a1; ++j)
+            if (tid[j] >= n_txps) { bad_tid[k] = j; break; }
+    };
+    if (nt == 1) {
+        scan(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; ++k) th.emplace_back(scan, k);
+        for (auto &t : th) t.join();
+    }
+    for (unsigned k = 0; k < nt; ++k)
+        if (bad_row[k] != kNone)
+            return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu", (unsigned long long)bad_row[k]);
     if (row_ptr[n_reads] != nnz)
         return fail(OEM_ERR_ARG, "row_ptr[n_reads]=%llu differs from nnz=%llu",
                     (unsigned long long)row_ptr[n_reads], (unsigned long long)nnz);
-    for (uint64_t j = 0; j < nnz; ++j)
-        if (tid[j] >= n_txps)
-            return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u", (unsigned long long)j,
-                        tid[j], n_txps);
+    for (unsigned k = 0; k < nt; ++k)
+        if (bad_tid[k] != kNone)
+            return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u", (unsigned long long)bad_tid[k],
+                        tid[bad_tid[k]], n_txps);
     return OEM_OK;
 }
 
@@ -153,12 +174,13 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
 
     // The stopping rule cannot fire before niter > gate, so the first look at
     // the device state is due after gate+2 passes; afterwards every `kChunk`.
-    uint32_t launched = 0;
-    constexpr uint32_t kChunk = 16;
+    uint64_t launched = 0;
+    constexpr uint64_t kChunk = 16;
     while (launched < a.max_iter) {
-        uint32_t chunk = launched == 0 ? a.min_iter_gate + 2 : kChunk;
+        uint64_t chunk = launched == 0 ? (uint64_t)a.min_iter_gate + 2 : kChunk; // (a gate of u32::MAX must not wrap)
         if (chunk > a.max_iter - launched) chunk = a.max_iter - launched;
-        for (uint32_t k = 0; k < chunk; ++k) OEM_TRY(enqueue_iteration(s, a, p));
+        if (chunk > 4096) chunk = 4096; // bound the work queued between two looks at the device state
+        for (uint64_t k = 0; k < chunk; ++k) OEM_TRY(enqueue_iteration(s, a, p));
         launched += chunk;
         OEM_HIP(hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream));
         OEM_HIP(hipStreamSynchronize(s->stream));
@@ -368,28 +390,7 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     t.n_rows = h.n_rows;
     t.n_local = h.n_local;
     t.n_remote = h.n_remote;
-    {
-        // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Descriptors are stored so that each
-        // XCD walks one contiguous eighth of the tiles: neighbouring tiles share theta-window lines
-        // and the partially filled queue lines at their run boundaries, which then meet in one L2.
-        static const int xcd_map = [] {
-            const char *e = getenv("OEM_TILE_XCD"); // tuning knob: 0 = descriptor order as built
-            return e ? atoi(e) : 0;
-        }();
-        if (xcd_map > 0 && h.n_tiles >= 64) {
-            const uint32_t n = h.n_tiles, nx = (uint32_t)xcd_map, chunk = (n + nx - 1) / nx;
-            std::vector<TileDesc> re;
-            re.reserve(n);
-            // position b holds tile (b % nx) * chunk + b / nx; positions whose tile does not exist are skipped
-            for (uint32_t b = 0; re.size() < n; ++b) {
-                const uint64_t ti = (uint64_t)(b % nx) * chunk + b / nx;
-                if (ti < n) re.push_back(h.tiles[ti]);
-            }
-            OEM_TRY(upload_vec(&t.tiles, re, &s->hbm_bytes));
-        } else {
-            OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
-        }
-    }
+    OEM_TRY(upload_vec(&t.tiles, h.tiles, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.perm, h.perm, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.codes, h.codes, &s->hbm_bytes));
     if (s->csr.w_is_f64) {
@@ -418,6 +419,13 @@ struct CellRelabel {
     uint32_t n_cells;
     uint32_t cell_txps;
 };
+
+__global__ __launch_bounds__(256) void k_narrow_u64(const unsigned long long *__restrict__ in, uint32_t *__restrict__ out,
+                                                    uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)in[i];
+}
 
 __global__ __launch_bounds__(256) void k_relabel_cells(const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ tid,
                                                        const unsigned long long *__restrict__ cell_row_off,
@@ -458,12 +466,25 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
             m.row_ptr = d;
             OEM_HIP(hipMemcpy(d, row_ptr, sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice));
         } else {
-            std::vector<uint32_t> rp(n_reads + 1);
-            for (uint64_t i = 0; i <= n_reads; ++i) rp[i] = (uint32_t)row_ptr[i];
+            // fewer than 2^32 alignments: the kernels walk u32 row pointers; narrowed on the device
+            // (no second host copy of the array)
+            unsigned long long *d64 = nullptr;
+            OEM_HIP(hipMalloc((void **)&d64, sizeof(uint64_t) * (n_reads + 1)));
             uint32_t *d = nullptr;
-            OEM_TRY(dev_alloc(&d, n_reads + 1, &s->hbm_bytes));
+            int rc = dev_alloc(&d, n_reads + 1, &s->hbm_bytes);
             m.row_ptr = d;
-            OEM_HIP(hipMemcpy(d, rp.data(), sizeof(uint32_t) * (n_reads + 1), hipMemcpyHostToDevice));
+            hipError_t e = rc == OEM_OK ? hipMemcpy(d64, row_ptr, sizeof(uint64_t) * (n_reads + 1), hipMemcpyHostToDevice)
+                                        : hipSuccess;
+            if (rc == OEM_OK && e == hipSuccess) {
+                const uint64_t n = n_reads + 1;
+                uint64_t g = (n + 255) / 256;
+                if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(k_narrow_u64, dim3((uint32_t)g), dim3(256), 0, s->stream, d64, d, n);
+                e = hipStreamSynchronize(s->stream);
+            }
+            hipFree(d64);
+            if (rc != OEM_OK) return rc;
+            if (e != hipSuccess) return fail(OEM_ERR_HIP, "row_ptr upload failed: %s", hipGetErrorString(e));
         }
         OEM_TRY(dev_alloc(&m.tid, nnz, &s->hbm_bytes));
         OEM_HIP(hipMemcpy(m.tid, tid, sizeof(uint32_t) * nnz, hipMemcpyHostToDevice));
@@ -498,7 +519,6 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     // Window cap of the tiles: sparse stores (few reads per transcript, e.g. per-cell batches) fill
     // their tiles only with a wide window; dense ones are faster with the narrow one and four copies.
     uint32_t win_cap = opts ? opts->window_cap : 0u;
-    if (const char *e = getenv("OEM_WIN_CAP")) win_cap = (uint32_t)atoi(e); // tuning knob
     if (win_cap != kWin && win_cap != kWinWide) {
         // measured (scripts/wincap_ab.py): the wide cap wins on large sparse stores (2 M reads over 4 M
         // transcripts -10 %, a 625-cell batch -16 %), the narrow one on dense stores and on small ones,
@@ -537,9 +557,8 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     };
     // The layout is built on the device from the resident CSR (oem_layout_device.hip); the host
     // builder (oem_layout.cpp, the specification) takes the stores that one does not, or all of them
-    // with OEM_LAYOUT_BUILD=host.
-    const char *lb = getenv("OEM_LAYOUT_BUILD");
-    if (!(lb && lb[0] == 'h')) {
+    // with oem_store_opts.layout_build = 1.
+    if (!(opts && opts->layout_build == 1)) {
         OEM_TRY(upload_csr());
         OEM_TRY(relabel_on_device());
         tm.lap("caller-order CSR upload");
@@ -670,49 +689,6 @@ extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint
         // nnz*(4 [tid] + 4|8 [w]) + (R+1)*4|8 [row_ptr] + 2*T*8 [theta read, cnt written]
         *algorithmic_bytes_per_pass = m.nnz * (4 + (m.w_is_f64 ? 8 : 4)) +
                                       (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) + 2ull * m.n_txps * 8;
-    return OEM_OK;
-}
-
-// Test hook (not in the public header): 64-bit hashes of the resident tiled layout, so that the
-// device-built layout can be checked element for element against the host-built one.
-// out[0..3] = n_tiles, n_rows, n_local, n_remote; out[4..13] = tiles, perm, codes, w, r_tid, r_w,
-// r_row, r_slot, q_dst, bucket_base; out[14] (if asked for) = 1 when the device built it; returns OEM_ERR_STATE when the store has no tiled layout.
-extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out)
-{
-    if (!s || !out || n_out < 14) return fail(OEM_ERR_ARG, "oem_debug_layout_hash: bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
-    OEM_TRY(ensure_device(s->device));
-    const DeviceTiled &t = s->tiled;
-    if (!t.present) return fail(OEM_ERR_STATE, "oem_debug_layout_hash: no tiled layout");
-    auto hash_dev = [&](const void *d, size_t bytes, uint64_t *h) -> int {
-        std::vector<uint64_t> buf((bytes + 7) / 8, 0);
-        if (bytes) OEM_HIP(hipMemcpy(buf.data(), d, bytes, hipMemcpyDeviceToHost));
-        uint64_t x = 0x9e3779b97f4a7c15ull ^ bytes;
-        for (uint64_t v : buf) { x ^= v; x *= 0xff51afd7ed558ccdull; x ^= x >> 29; }
-        *h = x;
-        return OEM_OK;
-    };
-    // array lengths follow from the descriptors: slices and remote records end with the last tile
-    uint64_t w_slots = 0, c_slots = 0;
-    if (t.n_tiles) {
-        TileDesc last;
-        OEM_HIP(hipMemcpy(&last, t.tiles + (t.n_tiles - 1), sizeof(last), hipMemcpyDeviceToHost));
-        w_slots = last.w_base; c_slots = last.c_base;
-        for (uint32_t i = 0; i < kTileSlices; ++i) { w_slots += last.width[i]; c_slots += (last.width[i] + 1u) / 2; }
-    }
-    out[0] = t.n_tiles; out[1] = t.n_rows; out[2] = t.n_local; out[3] = t.n_remote;
-    const size_t wsz = s->csr.w_is_f64 ? 8 : 4;
-    OEM_TRY(hash_dev(t.tiles, sizeof(TileDesc) * t.n_tiles, &out[4]));
-    OEM_TRY(hash_dev(t.perm, 4 * t.n_rows, &out[5]));
-    OEM_TRY(hash_dev(t.codes, 4 * (c_slots + 1) * 64, &out[6]));
-    OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.w64 : (const void *)t.w32, wsz * (w_slots + 1) * 64, &out[7]));
-    OEM_TRY(hash_dev(t.r_tid, 4 * t.n_remote, &out[8]));
-    OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.r_w64 : (const void *)t.r_w32, wsz * t.n_remote, &out[9]));
-    OEM_TRY(hash_dev(t.r_row, 2 * t.n_remote, &out[10]));
-    OEM_TRY(hash_dev(t.r_slot, 4 * t.n_remote, &out[11]));
-    OEM_TRY(hash_dev(t.q_dst, 2 * t.n_remote, &out[12]));
-    OEM_TRY(hash_dev(t.bucket_base, 4 * ((size_t)t.n_buckets + 1), &out[13]));
-    if (n_out > 14) out[14] = t.built_on_device ? 1 : 0;
     return OEM_OK;
 }
 
@@ -888,7 +864,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     if (!s) return fail(OEM_ERR_OOM, "oem_em_run_cells: host allocation failed");
     oem_store_opts opts;
     std::memset(&opts, 0, sizeof(opts));
-    opts.reorder_rows = 2;
+    opts.reorder_rows = 0; // a batch that cannot be tiled falls through to the cell-by-cell path
     opts.problem_size = n_txps;
     // transcripts of cell p -> [p*T, (p+1)*T), relabelled on the device after the upload
     CellRelabel rl{cell_row_off, n_cells, n_txps};
@@ -896,6 +872,10 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     if (rc != OEM_OK) {
         free_store(s);
         return rc;
+    }
+    if (!s->tiled.present) { // e.g. a read with > 255 alignments inside one window: the serial path takes the group
+        free_store(s);
+        return OEM_OK;
     }
     *used = true;
     tm.lap("cells: store create");
@@ -927,15 +907,20 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             }
             if ((rc2 = launch_multi_init(s, s->theta, d_reads, mb)) != OEM_OK) break;
             EmParams p{n_txps, max_iter, 50u /* em::em, single_cell.rs:150 */, conv_thresh};
-            const uint32_t total = max_iter + 1;
-            // one workgroup per bucket folds the queue AND finishes the pass (A/B knob: OEM_CELLS_FUSED_FOLD=0)
-            const char *ff = getenv("OEM_CELLS_FUSED_FOLD");
-            const bool fused_fold = !(ff && ff[0] == '0');
-            uint32_t launched = 0, unfinished = n_cells;
+            if (hipMemsetAsync(mb.out, 0, sizeof(double) * total_txps, s->stream) != hipSuccess) {
+                rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: clearing the result buffer failed");
+                break;
+            }
+            const uint64_t total = (uint64_t)max_iter + 1; // loop passes + the final one (em.rs:245-252)
+            // one workgroup per bucket folds the queue AND finishes the pass (k_multi_fold_reldiff); a
+            // store without remote alignments has no buckets to own and takes the separate kernels
+            const bool fused_fold = s->tiled.n_remote > 0 && s->tiled.n_buckets > 0 && knob("OEM_CELLS_FUSED_FOLD", 1) != 0;
+            uint64_t launched = 0;
+            uint32_t unfinished = n_cells;
             while (launched < total && unfinished) {
-                uint32_t chunk = launched == 0 ? 53 : 16;
+                uint64_t chunk = launched == 0 ? 53 : 16;
                 if (chunk > total - launched) chunk = total - launched;
-                for (uint32_t k = 0; k < chunk && rc2 == OEM_OK; ++k) {
+                for (uint64_t k = 0; k < chunk && rc2 == OEM_OK; ++k) {
                     if (fused_fold) {
                         rc2 = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, mb.state, n_txps, true);
                         if (rc2 == OEM_OK) rc2 = launch_multi_fold_reldiff(s, s->theta, s->cnt, mb, p);
@@ -997,14 +982,13 @@ int run_cells_group(const uint64_t *cell_row_off, uint32_t c0, uint32_t c1, cons
     double *out_g = out + (uint64_t)c0 * n_txps;
     oem_run_info *infos_g = infos ? infos + c0 : nullptr;
 
-    static const bool serial_cells = getenv("OEM_SERIAL_CELLS") != nullptr; // A/B knob
-    if (!serial_cells) {
+    if (knob("OEM_SERIAL_CELLS", 0) == 0) { // testing build: force the cell-by-cell path
         bool used = false;
         int rcb = run_cells_batched(off.data(), n_cells, rp.data(), tid_g, p_g, cov_g, n_reads, nnz, n_txps, device,
                                     max_iter, conv_thresh, out_g, infos_g, &used);
         if (rcb != OEM_OK || used) return rcb;
     }
-    // fallback (max_iter == 0 or a single cell): cells one after another
+    // fallback (max_iter == 0, a single cell, or a group the tiler declines): cells one after another
     oem_store *s = nullptr;
     oem_store_opts opts;
     std::memset(&opts, 0, sizeof(opts));
@@ -1053,8 +1037,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
     // Cells are independent problems, so a large experiment is cut into groups of consecutive cells
     // that bound the batched store (transcript space < 2^32, <= 2^30 alignments, and the layout
     // builder's tile x bucket table); each group is one batched run on the device.
-    const char *group_env = getenv("OEM_CELLS_GROUP_NNZ"); // tuning / test knob, read per call
-    const uint64_t max_group_nnz = group_env ? (uint64_t)atoll(group_env) : (1ull << 30);
+    const uint64_t max_group_nnz = (uint64_t)knob("OEM_CELLS_GROUP_NNZ", 1l << 30); // testing build: small groups
     uint32_t c0 = 0;
     while (c0 < n_cells) {
         uint32_t c1 = c0 + 1;
@@ -1068,7 +1051,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
             const bool wide = reads < 2 * cells * n_txps && reads >= 1000000; // as create_store_impl chooses
             const uint64_t tiles_est = reads / (wide ? 600 : 256) + 2 * cells;
             if (cells * n_txps >= (1ull << 32) || reads >= (1ull << 32) || gnnz > max_group_nnz ||
-                tiles_est * buckets > (1ull << 28))
+                tiles_est * buckets > (1ull << 28) || cells > 65535 /* gridDim.y of the per-cell kernels */)
                 break;
             ++c1;
         }

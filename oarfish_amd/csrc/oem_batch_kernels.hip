@@ -437,10 +437,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    static const int variant = [] {
-        const char *e = getenv("OEM_BATCH_VARIANT"); // tuning knob
-        return e ? atoi(e) : 0;
-    }();
+    const int variant = (int)knob("OEM_BATCH_VARIANT", 0); // testing build only
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * 6 + t.n_remote * 14;
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
 #define OEM_TILE_B_NT(TH, REM, NC, MW, NT)                                                                \

@@ -76,6 +76,7 @@ const char *nccl_err(ncclResult_t r)
 
 } // namespace
 
+#ifdef OEM_TESTING
 // Test backend (oem_debug_local_comm_create): the ranks are threads of ONE process that share a
 // GPU, and the "collective" is a host-side rendezvous plus one summing kernel.  It exists so that the
 // native sharded loop (global read count, per-pass exchange, identical stopping decision, sharded
@@ -108,14 +109,19 @@ __global__ void k_local_sum(const double *const *send, int n, double *out, size_
     }
 }
 
+#endif // OEM_TESTING
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0;
     int n_ranks = 1;
     int device = 0;
-    std::shared_ptr<LocalGroup> local;
+#ifdef OEM_TESTING
+    std::shared_ptr<LocalGroup> local; // test-only library: ranks are threads of one process
+#endif
 };
 
+#ifdef OEM_TESTING
 static int local_allreduce(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
 {
     LocalGroup &g = *c->local;
@@ -144,10 +150,13 @@ static int local_allreduce(Comm *c, const double *send, double *recv, size_t cou
     g.barrier(); // every rank's recv is written
     return rc;
 }
+#endif // OEM_TESTING
 
 int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
 {
+#ifdef OEM_TESTING
     if (c && c->local) return local_allreduce(c, send, recv, count, st);
+#endif
     if (!c || !c->comm) { // no exchange partner
         if (send != recv)
             OEM_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -160,7 +169,11 @@ int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t cou
 
 int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }
+#ifdef OEM_TESTING
 bool comm_exchanges(const Comm *c) { return c && (c->comm || c->local); }
+#else
+bool comm_exchanges(const Comm *c) { return c && c->comm; }
+#endif
 
 } // namespace oem
 
@@ -211,6 +224,7 @@ extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int
     return OEM_OK;
 }
 
+#ifdef OEM_TESTING
 // Test hook (not in the public header): n_ranks communicators of one process-local group.
 extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **out /* [n_ranks] */)
 {
@@ -230,6 +244,7 @@ extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **o
     }
     return OEM_OK;
 }
+#endif // OEM_TESTING
 
 extern "C" void oem_comm_destroy(oem_comm *comm)
 {

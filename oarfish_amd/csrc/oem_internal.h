@@ -33,6 +33,10 @@ int fail(int code, const char *fmt, ...);
         if (_rc != OEM_OK) return _rc; \
     } while (0)
 
+// Tuning / test switch (oem_knobs.cpp): the product library always returns `dflt`; only the
+// test-only library built with -DOEM_TESTING reads the environment variable `name`.
+long knob(const char *name, long dflt);
+
 // ---------------------------------------------------------------------------
 // Device-resident loop state of one EM problem (em.rs:169-170 rel_diff, niter).
 // Lives in HBM so that the host never sits inside the iteration loop: the

@@ -80,17 +80,8 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
 #pragma unroll
     for (int g = 0; g < kCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-#ifdef OEM_ABL_BYTEW // timing experiment: one byte per weight (values are garbage)
-            if constexpr (sizeof(WT) == 4) {
-                const uint16_t b = ld_stream<kNT>(&reinterpret_cast<const uint16_t *>(wbase)[g * 64 + lane]);
-                r.w[2 * g] = __uint_as_float(b & 255u);
-                r.w[2 * g + 1] = __uint_as_float((uint32_t)b >> 8);
-            } else
-#endif
-            {
-                r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
-                r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
-            }
+            r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
+            r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
             r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
         } else {
             r.w[2 * g] = (WT)0;
@@ -100,42 +91,27 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
     }
 }
 
-template <typename WT, int kCh, int kCopies, int kSched>
+template <typename WT, int kCh, int kCopies>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
                                            const double *theta_l, double *cnt_l, double *den_l,
-                                           const uint32_t *__restrict__ row_w_perm, uint32_t ablate)
+                                           const uint32_t *__restrict__ row_w_perm)
 {
     const uint32_t rl = s * 64 + lane;
-    if (kSched & 1) __builtin_amdgcn_sched_barrier(0);
-    if (kSched & 4) {
-        // Land every operand of this slice here (the loads of the NEXT slice stay in flight):
-        // one counted s_waitcnt in front of the fold instead of a wait per alignment woven
-        // through the LDS traffic.  Measured: 0.272 -> 0.237 ms per pass at C3.
+    __builtin_amdgcn_sched_barrier(0);
+    // Land every operand of this slice here (the loads of the NEXT slice stay in flight):
+    // one counted s_waitcnt in front of the fold instead of a wait per alignment woven
+    // through the LDS traffic.  Measured: 0.272 -> 0.237 ms per pass at C3.
 #pragma unroll
-        for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
+    for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
 #pragma unroll
-        for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
-    }
+    for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
     // the second element of the last pair of an odd-width slice belongs to the next row: it must
     // carry no weight.  Done once here, so the passes below need no per-alignment select.
     WT wz[kCh];
 #pragma unroll
     for (int k = 0; k < kCh; ++k) wz[k] = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : cur.w[k];
-#ifdef OEM_ABL_BYTEW
-    if constexpr (sizeof(WT) == 4) {
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) wz[k] = reinterpret_cast<const float *>(theta_l)[__float_as_uint(cur.w[k]) & 255u];
-    }
-#endif
-    if (ablate & 16) { // timing experiment: consume the operands, nothing else
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) acc += (float)cur.w[k] + (float)cur.c[k >> 1];
-        den_l[rl] = acc;
-        return;
-    }
     double x[kCh];
     double denom = den_l[rl];
 #pragma unroll
@@ -153,8 +129,6 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
     const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
     den_l[rl] = inv;
-    if (ablate & 2) return;
-    if (kSched & 2) __builtin_amdgcn_sched_barrier(0);
 
     // The count window is kept in kCopies interleaved copies (entry c of copy p at
     // (c * kCopies + p) * 8): lanes of different copies that add into the same
@@ -191,22 +165,15 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kUpfront, int kSched,
-          bool kNT, uint32_t kWinT = kWin>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT = kWin>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
-    const EmState *state, const uint32_t *__restrict__ row_w_perm, uint32_t ablate_arg,
+    const EmState *state, const uint32_t *__restrict__ row_w_perm,
     const BatchState *__restrict__ problems)
 {
-#ifdef OEM_TILE_ABLATION // timing experiments only (profiles/r01_notes.md); never in a product build
-    const uint32_t ablate = ablate_arg;
-#else
-    constexpr uint32_t ablate = 0;
-    (void)ablate_arg;
-#endif
     if (state && state->done) return;
 
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
@@ -239,13 +206,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
 
     // ---- every long-latency load of the tile is issued here, before any use ---------
-    // kUpfront: all slices of the wavefront are loaded here; otherwise the first one is, and
-    // the rest are prefetched one slice ahead of the fold (two register sets, ping-pong).
-    constexpr uint32_t kSets = kUpfront ? kPerWave : (kPerWave > 1 ? 2 : 1);
+    // The first slice of the wavefront is loaded here; the rest are prefetched one slice ahead of
+    // the fold (two register sets, ping-pong).
+    constexpr uint32_t kSets = kPerWave > 1 ? 2 : 1;
     SliceRegs<WT, kCh> R[kSets];
-#pragma unroll
-    for (uint32_t q = 0; q < (kUpfront ? kPerWave : 1u); ++q)
-        load_slice<WT, kCh, kNT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+    load_slice<WT, kCh, kNT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -253,7 +218,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     {
         uint32_t rt[kRem];
         WT rw[kRem];
-        if (td.remote_cnt && !(ablate & 1)) { // wave-uniform
+        if (td.remote_cnt) { // wave-uniform
             // branch-free: out-of-range slots re-read the tile's last record and carry no weight,
             // so the 4 x kRem loads issue back to back
             const uint32_t last = td.remote_cnt - 1;
@@ -261,10 +226,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-                if (!(ablate & 256)) {
-                    rt[k] = ld_stream<kNT>(&r_tid[o]);
-                    rw[k] = ld_stream<kNT>(&r_w[o]);
-                } else { rt[k] = 0; rw[k] = (WT)1; }
+                rt[k] = ld_stream<kNT>(&r_tid[o]);
+                rw[k] = ld_stream<kNT>(&r_w[o]);
                 rrow[k] = ld_stream<kNT>(&r_row[o]);
                 rslot[k] = ld_stream<kNT>(&r_slot[o]);
             }
@@ -276,61 +239,56 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) { rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0; }
         }
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) {
-            if (ablate & 256) rx[k] = (tx + k * kTileThreads < td.remote_cnt) ? queue[rslot[k]] : 0.0; // x staged by k_remote_x
-            else rx[k] = theta[(ablate & 128) ? (rt[k] & 7u) : rt[k]] * (double)rw[k];
+        for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
+    }
+    {
+        constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
+        double tw[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = tx + u * kTileThreads;
+            tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = tx + u * kTileThreads;
+            if (i < td.win_len) theta_l[i] = tw[u];
         }
     }
-    if (!(ablate & 32)) {
-        {
-            constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
-            double tw[kPer];
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) {
-                const uint32_t i = tx + u * kTileThreads;
-                tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) {
-                const uint32_t i = tx + u * kTileThreads;
-                if (i < td.win_len) theta_l[i] = tw[u];
-            }
-        }
-        for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
-        for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
-    }
-    if (!(ablate & 64)) __syncthreads();
+    for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
+    for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
+    __syncthreads();
 
     // ---- remote alignments, phase A: denominators --------------------------------
 #pragma unroll
     for (int k = 0; k < kRem; ++k)
-        if (tx + k * kTileThreads < td.remote_cnt && !(ablate & 1)) lds_add_f64(&den_l[rrow[k]], rx[k]);
+        if (tx + k * kTileThreads < td.remote_cnt) lds_add_f64(&den_l[rrow[k]], rx[k]);
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) { // overflow: park in the queue
         const uint32_t o = td.remote_begin + i;
         const double x = theta[r_tid[o]] * (double)r_w[o];
         queue[r_slot[o]] = x;
         lds_add_f64(&den_l[r_row[o]], x);
     }
-    if (!(ablate & 64)) __syncthreads();
+    __syncthreads();
 
     // ---- local alignments: one read per lane, all operands already in registers -----
 #pragma unroll
     for (uint32_t q = 0; q < kPerWave; ++q) {
         const uint32_t s = wave + kWaves * q;
-        if (!kUpfront && q + 1 < kPerWave)
+        if (q + 1 < kPerWave)
             load_slice<WT, kCh, kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies, kSched>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
-                       theta_l, cnt_l, den_l, row_w_perm, ablate);
+            fold_slice<WT, kCh, kCopies>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+                       theta_l, cnt_l, den_l, row_w_perm);
     }
-    if (!(ablate & 64)) __syncthreads();
+    __syncthreads();
 
     // ---- remote alignments, phase B: queue <- x * (c_i / denom_i) ------------------
 #pragma unroll
     for (int k = 0; k < kRem; ++k) {
         const uint32_t i = tx + k * kTileThreads;
-        if (i < td.remote_cnt && !(ablate & 9)) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
+        if (i < td.remote_cnt) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
     }
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
@@ -339,12 +297,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
 
     // ---- flush the window: consecutive lanes -> consecutive addresses ---------------
-    if (ablate & 32) return;
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         double v = 0.0;
 #pragma unroll
         for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
-        if (v != 0.0 && !(ablate & 4)) unsafeAtomicAdd(&cnt[td.lo + i], v);
+        if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
 }
 
@@ -398,37 +355,6 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     }
 }
 
-#ifdef OEM_TILE_ABLATION
-// Timing prototype (ablate bit 256): x = theta * w of the remote alignments computed bucket by bucket
-// with the theta bucket staged in LDS (as the fold kernel stages cnt), written to the queue; the tile
-// kernel then reads x from its queue slots instead of gathering theta from L2.
-__global__ __launch_bounds__(kFoldThreads) void k_remote_x(const uint32_t *__restrict__ bucket_base,
-                                                           double *__restrict__ queue, const uint16_t *__restrict__ q_dst,
-                                                           const float *__restrict__ q_w, const double *__restrict__ theta,
-                                                           uint32_t n_groups, uint32_t n_txps)
-{
-    __shared__ double th[kBucket];
-    const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
-    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
-    const uint64_t span = q1 - q0;
-    const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups), s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
-    if (s0 == s1) return;
-    const uint32_t base = b * kBucket;
-    for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreads) th[i] = base + i < n_txps ? theta[base + i] : 0.0;
-    __syncthreads();
-    uint32_t o = s0 + threadIdx.x;
-    for (; o + 3 * kFoldThreads < s1; o += 4 * kFoldThreads) {
-        uint32_t d[4];
-        float w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { d[k] = q_dst[o + k * kFoldThreads]; w[k] = q_w[o + k * kFoldThreads]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) queue[o + k * kFoldThreads] = th[d[k]] * (double)w[k];
-    }
-    for (; o < s1; o += kFoldThreads) queue[o] = th[q_dst[o]] * (double)q_w[o];
-}
-#endif
-
 __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restrict__ row_w,
                                                        const uint32_t *__restrict__ perm,
                                                        uint32_t *__restrict__ out, uint64_t n)
@@ -440,62 +366,24 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 
 } // namespace
 
-template <typename WT>
-static void launch_tile_variant(int variant, oem_store *s, const WT *w, const WT *r_w,
-                                const double *theta, double *cnt, const EmState *state,
-                                const uint32_t *row_w_perm, const BatchState *problems)
+// Register blocking of k_em_tile (profiles/r01_notes.md has the variants that were measured and
+// dropped): 256 threads, 4 slices per wavefront with one slice prefetched ahead, 8 local and 6
+// remote alignments per thread in registers; 4 interleaved count-window copies for the narrow
+// window cap, one for the wide cap of sparse stores (40 KiB LDS; same-address atomics are rare
+// when few reads share a transcript).
+template <typename WT, bool kNT>
+static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
+                        const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
 {
     const DeviceTiled &t = s->tiled;
-#ifdef OEM_TILE_ABLATION
-    static const uint32_t ablate = [] {
-        const char *e = getenv("OEM_TILE_ABLATE"); // timing experiments only: results are wrong when set
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-#else
-    constexpr uint32_t ablate = 0;
-#endif
-    // matrix bytes one pass streams; beyond the Infinity Cache they are loaded non-temporally
-    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (sizeof(WT) + 2) + t.n_remote * (sizeof(WT) + 10);
-    static const int nt_policy = [] {
-        const char *e = getenv("OEM_TILE_NT"); // tuning knob: 0 never, 1 always, unset = by size
-        return e ? atoi(e) : -1;
-    }();
-    const bool nt = nt_policy < 0 ? stream_bytes > (192ull << 20) : nt_policy != 0;
-    static const uint32_t pad_lds = [] {
-        const char *e = getenv("OEM_TILE_PAD_LDS"); // occupancy experiment: extra (unused) LDS bytes per workgroup
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-#define OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, NT)                                               \
-    hipLaunchKernelGGL((k_em_tile<WT, CH, REM, TH, MW, NC, UP, SC, NT>), dim3(t.n_tiles), dim3(TH), \
-                       pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, \
-                       theta, cnt, state, row_w_perm, ablate, problems)
-#define OEM_TILE(CH, REM, TH, MW, NC, UP, SC)                                                      \
-    do {                                                                                           \
-        if (nt) OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, true);                                    \
-        else OEM_TILE_NT(CH, REM, TH, MW, NC, UP, SC, false);                                      \
-    } while (0)
-    if (t.win_cap > kWin) {
-        // sparse store (window cap kWinWide): one count-window copy keeps the LDS at 40 KiB; same-address
-        // atomics are rare when few reads share a transcript (per-cell EM loop -16 % against 512 x 4)
-        if (nt)
-            hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, false, 5, true, kWinWide>), dim3(t.n_tiles), dim3(256),
-                               pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue,
-                               theta, cnt, state, row_w_perm, ablate, problems);
-        else
-            hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, false, 5, false, kWinWide>), dim3(t.n_tiles), dim3(256),
-                               pad_lds, s->stream, t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue,
-                               theta, cnt, state, row_w_perm, ablate, problems);
-        return;
-    }
-    switch (variant) {
-    case 1: OEM_TILE(8, 3, 512, 2, 4, true, 4); break;   // all slices up front, 8 waves
-    case 2: OEM_TILE(12, 6, 256, 2, 4, false, 4); break;
-    case 3: OEM_TILE(8, 3, 512, 2, 4, false, 4); break;
-    case 4: OEM_TILE(8, 6, 256, 2, 4, false, 0); break;  // without the operand-landing fence
-    default: OEM_TILE(8, 6, 256, 2, 4, false, 5); break; // 4 waves, 4 slices each, one slice prefetched ahead
-    }
-#undef OEM_TILE
-#undef OEM_TILE_NT
+    if (t.win_cap > kWin)
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+                           t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, theta, cnt, state,
+                           row_w_perm, problems);
+    else
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+                           t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, theta, cnt, state,
+                           row_w_perm, problems);
 }
 
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
@@ -503,44 +391,28 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    static const int variant = [] {
-        const char *e = getenv("OEM_TILE_VARIANT"); // tuning knob (register blocking of k_em_tile)
-        return e ? atoi(e) : 0;
-    }();
-#ifdef OEM_TILE_ABLATION
-    {
-        static const uint32_t abl = [] { const char *e = getenv("OEM_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
-        if ((abl & 256) && t.n_remote > 0 && !s->csr.w_is_f64) {
-            uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
-            if (n_groups < 1) n_groups = 1;
-            hipLaunchKernelGGL(k_remote_x, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0, s->stream, t.bucket_base,
-                               t.queue, t.q_dst, (const float *)t.r_w32, theta, n_groups, s->csr.n_txps);
-        }
+    const bool f64w = s->csr.w_is_f64;
+    // matrix bytes one pass streams; beyond the Infinity Cache they are loaded non-temporally
+    const uint64_t wsz = f64w ? 8 : 4;
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + 10);
+    const long nt_knob = knob("OEM_TILE_NT", -1); // testing build: 0 never, 1 always
+    const bool nt = nt_knob < 0 ? stream_bytes > (192ull << 20) : nt_knob != 0;
+    if (f64w) {
+        if (nt) launch_tile<double, true>(s, t.w64, t.r_w64, theta, cnt, state, row_w_perm, problems);
+        else launch_tile<double, false>(s, t.w64, t.r_w64, theta, cnt, state, row_w_perm, problems);
+    } else {
+        if (nt) launch_tile<float, true>(s, t.w32, t.r_w32, theta, cnt, state, row_w_perm, problems);
+        else launch_tile<float, false>(s, t.w32, t.r_w32, theta, cnt, state, row_w_perm, problems);
     }
-#endif
-    if (s->csr.w_is_f64)
-        launch_tile_variant<double>(variant, s, (const double *)t.w64, (const double *)t.r_w64, theta,
-                                    cnt, state, row_w_perm, problems);
-    else
-        launch_tile_variant<float>(variant, s, (const float *)t.w32, (const float *)t.r_w32, theta, cnt,
-                                   state, row_w_perm, problems);
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
         // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
-        // fewer, longer-running workgroups mean fewer flush atomics)
-        static const uint32_t fold_wgs = [] {
-            const char *e = getenv("OEM_FOLD_WGS"); // tuning knob
-            return e ? (uint32_t)atoi(e) : 256u;
-        }();
-        uint32_t n_groups = fold_wgs / (t.n_buckets ? t.n_buckets : 1);
+        // fewer, longer-running workgroups mean fewer flush atomics) ...
+        uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
         // ... but every workgroup clears and flushes a whole 64 KiB window, which only pays for
         // itself with >= 16 Ki queue entries to fold (1 M-read store: 32 Ki 34.5 us, 16 Ki 33.1 us, 8 Ki 35.6 us per pass)
         const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
-        static const uint64_t min_entries = [] {
-            const char *e = getenv("OEM_FOLD_MIN_ENTRIES"); // tuning knob
-            return e ? (uint64_t)atoll(e) : 16384ull;
-        }();
-        const uint32_t max_useful = (uint32_t)((per_bucket + min_entries - 1) / min_entries);
+        const uint32_t max_useful = (uint32_t)((per_bucket + 16383) / 16384);
         if (n_groups > max_useful) n_groups = max_useful;
         if (n_groups < 1) n_groups = 1;
         hipLaunchKernelGGL(k_remote_fold, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,

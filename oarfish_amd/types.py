@@ -53,7 +53,7 @@ class DeviceStore:
     """RAII wrapper of an ``oem_store*`` (the matrix resident in HBM on one GPU)."""
 
     def __init__(self, row_ptr, tid, as_prob, cov_prob, n_txps: int, device: int = 0,
-                 reorder_rows: int = 0):
+                 reorder_rows: int = 0, window_cap: int = 0, layout_build: int = 0):
         self._h = C.c_void_p()
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         tid = np.ascontiguousarray(tid, dtype=np.uint32)
@@ -67,17 +67,25 @@ class DeviceStore:
             raise ValueError("tid / as_prob / cov_prob lengths differ")
         opts = _lib.StoreOptsC()
         opts.reorder_rows = reorder_rows
+        opts.window_cap = window_cap      # 0 = chosen from the store; 512 / 2048 force it (oem_store_opts)
+        opts.layout_build = layout_build  # 1 = host layout builder (the specification)
         L = _lib.lib()
-        _lib.check(L.oem_store_create(
+        self._lib = L                     # the library that owns the handle
+        self._check(L.oem_store_create(
             self.row_ptr.ctypes.data, tid.ctypes.data if self.nnz else None,
             as_prob.ctypes.data if self.nnz else None,
             None if cov is None else cov.ctypes.data, self.n_reads, self.nnz, self.n_txps,
             self.device, C.addressof(opts), C.byref(self._h)))
 
+    def _check(self, rc: int) -> None:
+        if rc != _lib.OEM_OK:
+            msg = self._lib.oem_last_error()
+            raise _lib.OemError(rc, msg.decode("utf-8", "replace") if msg else "")
+
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            _lib.lib().oem_store_destroy(self._h)
+            self._lib.oem_store_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):  # pragma: no cover
@@ -101,11 +109,11 @@ class DeviceStore:
     # -- queries ----------------------------------------------------------
     def bytes(self) -> Tuple[int, int]:
         hbm, alg = C.c_uint64(0), C.c_uint64(0)
-        _lib.check(_lib.lib().oem_store_bytes(self.handle, C.byref(hbm), C.byref(alg)))
+        self._check(self._lib.oem_store_bytes(self.handle, C.byref(hbm), C.byref(alg)))
         return int(hbm.value), int(alg.value)
 
     def set_option(self, option: int, value: int):
-        _lib.check(_lib.lib().oem_store_set_option(self.handle, option, value))
+        self._check(self._lib.oem_store_set_option(self.handle, option, value))
 
     # -- compute ----------------------------------------------------------
     def m_step(self, theta, row_w=None) -> np.ndarray:
@@ -119,7 +127,7 @@ class DeviceStore:
             if len(row_w) != self.n_reads:
                 raise ValueError("row_w length != n_reads")
             wp = row_w.ctypes.data
-        _lib.check(_lib.lib().oem_m_step(self.handle, theta.ctypes.data, wp, out.ctypes.data))
+        self._check(self._lib.oem_m_step(self.handle, theta.ctypes.data, wp, out.ctypes.data))
         return out
 
     def em_run(self, init=None, max_iter=1000, conv_thresh=1e-3, min_iter_gate=50):
@@ -131,7 +139,7 @@ class DeviceStore:
             if len(init) != self.n_txps:
                 raise ValueError("init_abundances length != n_txps")
             ip = init.ctypes.data
-        _lib.check(_lib.lib().oem_em_run(self.handle, ip, max_iter, conv_thresh, min_iter_gate,
+        self._check(self._lib.oem_em_run(self.handle, ip, max_iter, conv_thresh, min_iter_gate,
                                          out.ctypes.data, C.byref(ri)))
         return out, RunInfo(ri.niter, ri.n_passes, bool(ri.converged), ri.rel_diff)
 
@@ -139,7 +147,7 @@ class DeviceStore:
         """aux_counts.rs:23-50 -> (unique_count u32[T], total_count u32[T])."""
         u = np.zeros(self.n_txps, dtype=np.uint32)
         t = np.zeros(self.n_txps, dtype=np.uint32)
-        _lib.check(_lib.lib().oem_aux_counts(self.handle, u.ctypes.data, t.ctypes.data))
+        self._check(self._lib.oem_aux_counts(self.handle, u.ctypes.data, t.ctypes.data))
         return u, t
 
     def assignment_probs(self, counts, display_thresh: float) -> np.ndarray:
@@ -148,13 +156,13 @@ class DeviceStore:
         if len(counts) != self.n_txps:
             raise ValueError("counts length != n_txps")
         out = np.zeros(self.nnz, dtype=np.float64)
-        _lib.check(_lib.lib().oem_assignment_probs(self.handle, counts.ctypes.data, display_thresh,
+        self._check(self._lib.oem_assignment_probs(self.handle, counts.ctypes.data, display_thresh,
                                                    out.ctypes.data))
         return out
 
     def bootstrap_weights(self, seed: int, replica: int) -> np.ndarray:
         w = np.zeros(self.n_reads, dtype=np.uint32)
-        _lib.check(_lib.lib().oem_bootstrap_weights(self.handle, seed, replica, w.ctypes.data))
+        self._check(self._lib.oem_bootstrap_weights(self.handle, seed, replica, w.ctypes.data))
         return w
 
     def bootstrap(self, n_boot: int, seed: int = 0, row_w_all=None, init=None, max_iter=1000,
@@ -174,24 +182,26 @@ class DeviceStore:
         ip = None
         if init is not None:
             init = np.ascontiguousarray(init, dtype=np.float64)
+            if len(init) != self.n_txps:
+                raise ValueError("init_abundances length != n_txps")
             ip = init.ctypes.data
-        _lib.check(_lib.lib().oem_bootstrap(self.handle, n_boot, seed, wp, ip, max_iter, conv_thresh,
+        self._check(self._lib.oem_bootstrap(self.handle, n_boot, seed, wp, ip, max_iter, conv_thresh,
                                             out.ctypes.data, C.addressof(infos)))
         return out, [RunInfo(i.niter, i.n_passes, bool(i.converged), i.rel_diff)
                      for i in list(infos)[:n_boot]]
 
     def time_m_step(self, n_launches: int) -> float:
         ms = C.c_float(0)
-        _lib.check(_lib.lib().oem_time_m_step(self.handle, n_launches, C.byref(ms)))
+        self._check(self._lib.oem_time_m_step(self.handle, n_launches, C.byref(ms)))
         return float(ms.value)
 
     def time_em_iters(self, n_iters: int) -> float:
         ms = C.c_float(0)
-        _lib.check(_lib.lib().oem_time_em_iters(self.handle, n_iters, C.byref(ms)))
+        self._check(self._lib.oem_time_em_iters(self.handle, n_iters, C.byref(ms)))
         return float(ms.value)
 
     def attach_comm(self, comm_handle, global_n_reads: int, global_row_offset: int):
-        _lib.check(_lib.lib().oem_store_attach_comm(self.handle, comm_handle, global_n_reads,
+        self._check(self._lib.oem_store_attach_comm(self.handle, comm_handle, global_n_reads,
                                                     global_row_offset))
 
 
@@ -284,7 +294,7 @@ class InMemoryAlignmentStore:
 
     # -- HBM-resident form ----------------------------------------------------
     def invalidate_device(self):
-        for d in self._dev.values():
+        for _stamp, d in self._dev.values():
             d.close()
         self._dev = {}
 
@@ -292,12 +302,22 @@ class InMemoryAlignmentStore:
         """Upload once, keep resident (the analogue of the store living in RAM across
         em / bootstrap calls, bulk.rs:131-194)."""
         self._flush()
+        cov = self.coverage_probabilities if self.filter_opts.model_coverage else None  # em.rs:108
+        # The reference mutates the store between calls (normalize_read_probs fills
+        # coverage_probabilities, bulk.rs:103-108): the resident copy is keyed by the identity of the
+        # arrays it was made from and by model_coverage, and re-made when any of them is replaced.
+        # (In-place writes into an array after its upload need an explicit invalidate_device().)
         key = (int(device), int(n_txps))
-        if key not in self._dev:
-            cov = self.coverage_probabilities if self.filter_opts.model_coverage else None  # em.rs:108
-            self._dev[key] = DeviceStore(self.boundaries, self.alignments, self.as_probabilities,
-                                         cov, n_txps, device)
-        return self._dev[key]
+        stamp = (id(self.boundaries), id(self.alignments), id(self.as_probabilities),
+                 None if cov is None else id(cov), bool(self.filter_opts.model_coverage))
+        hit = self._dev.get(key)
+        if hit is not None and hit[0] != stamp:
+            hit[1].close()
+            hit = None
+        if hit is None:
+            hit = (stamp, DeviceStore(self.boundaries, self.alignments, self.as_probabilities, cov, n_txps, device))
+            self._dev[key] = hit
+        return hit[1]
 
 
 @dataclass

@@ -84,3 +84,27 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("SURVEY", ""), f"{f} mentions the oracle"
+
+
+def test_product_library_carries_no_test_hooks_or_env_knobs(monkeypatch):
+    """liboarfish_em.so exports exactly the header's entry points: the debug / test hooks and the
+    environment-driven knobs exist only in liboarfish_em_testing.so (built with -DOEM_TESTING)."""
+    import subprocess
+    from oarfish_amd import build as _b
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+
+    prod, test = exported(_b.LIB_PATH), exported(_b.TESTING_LIB_PATH)
+    c_abi = {s for s in prod if s.startswith("oem_")}
+    assert c_abi == set(_header_symbols()), sorted(c_abi ^ set(_header_symbols()))
+    hooks = {"oem_debug_layout_hash", "oem_debug_local_comm_create", "oem_test_reldiff_stress"}
+    assert hooks <= test and not (hooks & prod)
+    # the knob function of the product ignores the environment (oem_knobs.cpp without OEM_TESTING)
+    monkeypatch.setenv("OEM_SELFTEST_KNOB", "7")
+    knob = "_ZN3oem4knobEPKcl"
+    for L, want in ((C.CDLL(_b.LIB_PATH), 3), (C.CDLL(_b.TESTING_LIB_PATH), 7)):
+        fn = getattr(L, knob)
+        fn.restype, fn.argtypes = C.c_long, [C.c_char_p, C.c_long]
+        assert fn(b"OEM_SELFTEST_KNOB", 3) == want

@@ -72,8 +72,7 @@ def test_hand_checked_read():
     _lib.lib().oem_builder_destroy(h)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_builder_matches_python_restatement(seed):
+def _builder_matches_python_restatement(seed):
     rng = np.random.default_rng(seed)
     T = 50
     txp_len = rng.integers(300, 4000, size=T)
@@ -102,6 +101,20 @@ def test_builder_matches_python_restatement(seed):
     assert np.array_equal(p.view(np.uint32), np.asarray(ref.as_prob, dtype=np.float32).view(np.uint32))  # bit-exact f32
     assert len(rp) - 1 > 20 and dt["discard_score"] + dt["discard_3p"] + dt["discard_5p"] > 0 and dt["no_valid_aln"] > 0
     _lib.lib().oem_builder_destroy(h)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_builder_matches_python_restatement(seed):
+    _builder_matches_python_restatement(seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_builder_matches_python_restatement_on_the_gpu_box(seed):
+    """The same bit-exact f32 / discard-table comparison of oem_builder_add_group with
+    oracle/filter_py.add_group (oarfish_types.rs:955-1130), run by the driver's GPU tier as well:
+    host code, but it is the library build the GPU box loads that is being checked."""
+    _builder_matches_python_restatement(seed)
 
 
 @pytest.mark.gpu
@@ -320,3 +333,56 @@ def test_records_to_abundances_with_coverage_model():
     assert abs(ri.niter - wi.niter) <= 1
     np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-6)
     assert abs(out.sum() - (len(rp) - 1)) < 1e-6 * len(rp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,seed,bin_width,growth", [("logistic", 25, 100, 2.0), ("logistic", 26, 40, 0.8),
+                                                          ("binomial", 27, 100, 0.0), ("binomial", 28, 230, 0.0)])
+def test_device_coverage_model_matches_the_oracle(model, seed, bin_width, growth):
+    """oem_coverage_probs_device (both coverage models, oem_coverage_device.hip) directly against the
+    ORACLE (oracle/filter_py.coverage_probs: add_interval binning oarfish_types.rs:496-538, logistic_prob
+    logistic_probability.rs:41-79, binomial_continuous_prob binomial_probability.rs:170-224,
+    normalize_read_probs normalize_probability.rs:5-74) -- not against the library's own host functions.
+    The device sums the bins with f64 atomics: equal to rounding, and to ~1e-7 where a bin count sits on
+    an f32 rounding boundary (the reference truncates the counts to f32, oarfish_types.rs:478)."""
+    rng = np.random.default_rng(seed)
+    T = 35
+    txp_len = rng.integers(500, 4500, size=T)
+    F = fp.Filters()
+    h = _builder(F, txp_len)
+    ref = fp.Store()
+    for _ in range(1400):
+        t0 = int(rng.integers(0, T))
+        g = []
+        for j in range(int(rng.integers(1, 5))):
+            t = int((t0 + j) % T)
+            L = int(txp_len[t])
+            start = int(rng.integers(0, max(1, L - 120)))
+            end = int(rng.integers(start + 100, L + 1)) if start + 100 <= L else L
+            span = end - start
+            g.append(fp.Rec(t, start, end, span, 2000 - int(rng.integers(0, 40)) * (j > 0), 1000 if span >= 600 else max(span, 1)))
+        assert _add(h, g) == fp.add_group(ref, F, txp_len, g)
+    rp, tid, p, s, e, sd, dt = _export(h)
+    nnz = len(tid)
+    assert nnz > 1000
+    want = np.asarray(fp.coverage_probs(ref, txp_len, bin_width, growth, model=model))
+    m = 0 if model == "logistic" else 1
+    # through the builder handle ...
+    got = np.zeros(nnz)
+    _lib.check(_lib.lib().oem_builder_coverage_probs_device(h, bin_width, m, growth, 0, got.ctypes.data))
+    _lib.lib().oem_builder_destroy(h)
+    # ... and from raw arrays (the exported CSR + coordinates)
+    raw = np.zeros(nnz)
+    tl = np.ascontiguousarray(txp_len, dtype=np.uint64)
+    s32, e32 = np.ascontiguousarray(s, dtype=np.uint32), np.ascontiguousarray(e, dtype=np.uint32)
+    rp64, tid32 = np.ascontiguousarray(rp, dtype=np.uint64), np.ascontiguousarray(tid, dtype=np.uint32)
+    _lib.check(_lib.lib().oem_coverage_probs_device(rp64.ctypes.data, tid32.ctypes.data, s32.ctypes.data, e32.ctypes.data,
+                                                    tl.ctypes.data, len(rp64) - 1, nnz, T, bin_width, m, growth, 0,
+                                                    raw.ctypes.data))
+    for what, out in (("builder handle", got), ("raw arrays", raw)):
+        np.testing.assert_allclose(out, want, rtol=2e-6, atol=1e-300, err_msg=what)
+        assert np.median(np.abs(out - want) / np.maximum(want, 1e-300)) < (1e-12 if m == 0 else 1e-9), what
+    sums = np.add.reduceat(got, rp64[:-1].astype(np.int64))
+    live = sums > 0
+    np.testing.assert_allclose(sums[live], 1.0, rtol=1e-12)      # normalised per read
+    assert live.mean() > 0.9

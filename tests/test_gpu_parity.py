@@ -206,12 +206,22 @@ def test_cells_match_per_cell_oracle():
         assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
 
 
-def _layout_hash(row_ptr, tid, p, cov, T, problem_size=0):
+def _layout_hash(row_ptr, tid, p, cov, T, problem_size=0, win_cap=0, host_build=False):
+    """Hashes of the resident tiled arrays (hook of the test-only library)."""
+    import ctypes as C
+    from oarfish_amd import _lib
+    with _lib.testing():
+        return _layout_hash_impl(row_ptr, tid, p, cov, T, problem_size, win_cap, host_build)
+
+
+def _layout_hash_impl(row_ptr, tid, p, cov, T, problem_size, win_cap, host_build):
     import ctypes as C
     from oarfish_amd import _lib
     opts = _lib.StoreOptsC()
     opts.problem_size = problem_size
     opts.reorder_rows = 2 if problem_size else 0
+    opts.window_cap = int(win_cap)
+    opts.layout_build = 1 if host_build else 0
     h = C.c_void_p()
     row_ptr = np.ascontiguousarray(row_ptr, np.uint64); tid = np.ascontiguousarray(tid, np.uint32)
     p = np.ascontiguousarray(p, np.float32)
@@ -221,7 +231,6 @@ def _layout_hash(row_ptr, tid, p, cov, T, problem_size=0):
                                            C.byref(opts), C.byref(h)))
     out = (C.c_uint64 * 15)()
     fn = _lib.lib().oem_debug_layout_hash
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     try:
         _lib.check(fn(h, C.addressof(out), 15))
     finally:
@@ -233,9 +242,9 @@ LAYOUT_FIELDS = ["n_tiles", "n_rows", "n_local", "n_remote", "tiles", "perm", "c
                  "r_slot", "q_dst", "bucket_base"]
 
 
-@pytest.mark.parametrize("win_cap", ["512", "2048"])
+@pytest.mark.parametrize("win_cap", [512, 2048])
 @pytest.mark.parametrize("case", ["medium", "coverage", "sparse_wide", "tiny", "empty_rows_dups", "cells", "c2"])
-def test_device_built_layout_equals_host_built_layout(case, win_cap, monkeypatch):
+def test_device_built_layout_equals_host_built_layout(case, win_cap):
     """oem_layout_device.hip against its specification (oem_layout.cpp): every array of the tiled layout,
     element for element (64-bit hashes of the resident arrays), over dense / sparse / ragged stores, the
     f64 coverage weights and the per-cell problem boundaries."""
@@ -265,11 +274,8 @@ def test_device_built_layout_equals_host_built_layout(case, win_cap, monkeypatch
         ps, T = T, 9 * T
     else:
         st = synth.make_store(1_000_000, 60_000, seed=synth.BASE_SEED); rp, tid, p, T = st.row_ptr, st.tid, st.as_prob, st.n_txps
-    monkeypatch.setenv("OEM_WIN_CAP", win_cap)
-    monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
-    want = _layout_hash(rp, tid, p, cov, T, ps)
-    monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")
-    got = _layout_hash(rp, tid, p, cov, T, ps)
+    want = _layout_hash(rp, tid, p, cov, T, ps, win_cap, host_build=True)
+    got = _layout_hash(rp, tid, p, cov, T, ps, win_cap)
     assert want[14] == 0 and got[14] == 1, "the two builders were not the ones asked for"
     diff = [f for f, a, b in zip(LAYOUT_FIELDS, got, want) if a != b]
     assert not diff, f"{case}: device-built layout differs from the host-built one in {diff} ({got[:4]} vs {want[:4]})"
@@ -277,7 +283,7 @@ def test_device_built_layout_equals_host_built_layout(case, win_cap, monkeypatch
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_device_built_layout_equals_host_built_layout_random_shapes(seed, monkeypatch):
+def test_device_built_layout_equals_host_built_layout_random_shapes(seed):
     """Same equality over randomly shaped stores: read lengths up to 120, 1..300 k transcripts, repeats,
     empty reads, optional coverage weights, optional per-problem boundaries."""
     rng = np.random.default_rng(7000 + seed)
@@ -298,12 +304,11 @@ def test_device_built_layout_equals_host_built_layout_random_shapes(seed, monkey
         tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
     p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
     cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 4 == 0 else None
+    win_cap = 0                                          # chosen from the density
     if seed % 2:
-        monkeypatch.setenv("OEM_WIN_CAP", "2048" if seed % 4 == 1 else "512")   # else: chosen from the density
-    monkeypatch.setenv("OEM_LAYOUT_BUILD", "host")
-    want = _layout_hash(rp, tid, p, cov, T, ps)
-    monkeypatch.setenv("OEM_LAYOUT_BUILD", "device")
-    got = _layout_hash(rp, tid, p, cov, T, ps)
+        win_cap = 2048 if seed % 4 == 1 else 512
+    want = _layout_hash(rp, tid, p, cov, T, ps, win_cap, host_build=True)
+    got = _layout_hash(rp, tid, p, cov, T, ps, win_cap)
     what = f"seed {seed}: R={R} T={T} maxk={maxk} ps={ps} cov={cov is not None}"
     assert want[14] == 0 and got[14] == 1, what
     diff = [f for f, a, b in zip(LAYOUT_FIELDS, got, want) if a != b]
@@ -331,8 +336,12 @@ def test_cells_ragged_batch(group_nnz, monkeypatch):
     """Cells of very different sizes (incl. an empty one and a one-read one), with the coverage column:
     every cell stops at its own iteration.  With a small group bound the experiment is cut into several
     batched groups (and single-cell groups take the cell-by-cell path): results must not depend on it."""
-    if group_nnz:
+    import contextlib
+    from oarfish_amd import _lib
+    ctx = contextlib.nullcontext()
+    if group_nnz:   # the knob only exists in the test-only library; the product ignores the environment
         monkeypatch.setenv("OEM_CELLS_GROUP_NNZ", str(group_nnz))
+        ctx = _lib.testing()
     T = 900
     rng = np.random.default_rng(12)
     sizes = [4000, 0, 1, 700, 2500, 60]
@@ -346,7 +355,8 @@ def test_cells_ragged_batch(group_nnz, monkeypatch):
             base += st.nnz
         cell_off[c + 1] = cell_off[c] + np.uint64(n)
     row_ptr, tid, p, cov = np.concatenate(rps), np.concatenate(tids), np.concatenate(ps), np.concatenate(covs)
-    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, cov, T, max_iter=400, convergence_thresh=1e-3)
+    with ctx:
+        out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, cov, T, max_iter=400, convergence_thresh=1e-3)
     niters = []
     for c, n in enumerate(sizes):
         r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
@@ -536,17 +546,21 @@ def test_bootstrap_first_replica_splits_a_replicate_set():
 def test_native_sharded_loop_with_several_shards_on_one_gpu(world):
     """The native row-sharded loop (oem_em_run / oem_bootstrap on stores with an attached communicator)
     with `world` real shards.  RCCL refuses two ranks per device, so the ranks are threads of this process
-    joined by the library's process-local test communicator (same call sites as RCCL: one sum of the count
+    joined by the process-local communicator of the TEST-ONLY library (same call sites as RCCL: one sum of the count
     vector per pass).  Results must equal the un-sharded store's and the oracle's, with identical iteration
     counts on every rank."""
+    from oarfish_amd import _lib
+    with _lib.testing():
+        _sharded_loop_body(world)
+
+
+def _sharded_loop_body(world):
     import ctypes as C
     import threading
     from oarfish_amd import _lib, dist as odist
     st = synth.make_store(90_000, 6_000, seed=611)
     handles = (C.c_void_p * world)()
-    fn = _lib.lib().oem_debug_local_comm_create
-    fn.argtypes = [C.c_int, C.c_int, C.c_void_p]
-    _lib.check(fn(world, 0, C.addressof(handles)))
+    _lib.check(_lib.lib().oem_debug_local_comm_create(world, 0, C.addressof(handles)))
     res, errs = [None] * world, []
 
     def rank_main(rank):
@@ -710,14 +724,13 @@ def test_read_with_more_than_255_window_alignments_takes_the_csr_path():
     p = np.exp(-rng.integers(0, 30, size=len(tid)) / 5.0).astype(np.float32)
     o = c_oracle.Store(rp, tid, p, None, T)
     want, wi = c_oracle.do_em(o, max_iter=150, conv_thresh=1e-3)
+    import ctypes as C
+    from oarfish_amd import _lib
+    with _lib.testing(), DeviceStore(rp, tid, p, None, T) as d:     # (the layout-hash hook lives in the test-only library)
+        out = (C.c_uint64 * 15)()
+        assert _lib.lib().oem_debug_layout_hash(d.handle, C.addressof(out), 15) == _lib.OEM_ERR_STATE  # no tiled layout
     with DeviceStore(rp, tid, p, None, T) as d:
         got, gi = d.em_run(None, 150, 1e-3, 50)
-        import ctypes as C
-        from oarfish_amd import _lib
-        out = (C.c_uint64 * 15)()
-        fn = _lib.lib().oem_debug_layout_hash
-        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-        assert fn(d.handle, C.addressof(out), 15) == _lib.OEM_ERR_STATE       # no tiled layout on this store
     assert abs(gi.niter - wi.niter) <= 1
     assert_counts_close(got, want, len(lens), T, RTOL if gi.niter != wi.niter else 1e-9, "CSR path")
 
@@ -771,14 +784,16 @@ def test_full_size_properties(name):
     o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
     u, t = c_oracle.aux_counts(o)
     with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
-        cnt, info = d.em_run(None, 100, 0.0, 50)          # 100 iterations, no early exit
-        assert info.niter == 100 and info.n_passes == 101 and not info.converged
+        # BASELINE configs[1]: 1000 EM iterations, no early exit, tolerance 1e-4 against the CPU
+        cnt, info = d.em_run(None, 1000, 0.0, 50)
+        assert info.niter == 1000 and info.n_passes == 1001 and not info.converged
         assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads       # mass conservation
         assert np.all(cnt >= u - 1e-6) and np.all(cnt <= t + 1e-6)   # unique <= count <= total
-        want, wi = c_oracle.em_par(o, max_iter=100, conv_thresh=0.0, min_iter_gate=50)
-        assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL, "c2 100 iterations")
+        want, wi = c_oracle.em_par(o, max_iter=1000, conv_thresh=0.0, min_iter_gate=50)
+        assert wi.niter == 1000
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL, "c2 1000 iterations")
         # idempotence of the resident store: a second run gives the same answer
-        cnt2, _ = d.em_run(None, 100, 0.0, 50)
+        cnt2, _ = d.em_run(None, 1000, 0.0, 50)
         assert_counts_close(cnt2, cnt, st.n_reads, st.n_txps, 1e-9, "rerun")
         # linearity of one pass in the row weights: E(w1) + E(w2) = E(w1 + w2)
         rng = np.random.default_rng(2)
@@ -787,3 +802,142 @@ def test_full_size_properties(name):
         theta = cnt + 1e-3
         a, b, c = d.m_step(theta, w1), d.m_step(theta, w2), d.m_step(theta, w1 + w2)
         assert_counts_close(a + b, c, st.n_reads, st.n_txps, 1e-9, "linearity")
+
+
+# ---------------------------------------------------------------------------------------------------
+# The wide-window instantiation of the tile kernel (k_em_tile<..., kWinWide>: window cap 2048, one
+# count-window copy) is what every large sparse store and every per-cell batch runs.  Forced here
+# through oem_store_opts.window_cap on stores of every shape, against the oracle.
+# ---------------------------------------------------------------------------------------------------
+WIDE = 2048
+
+
+@pytest.mark.parametrize("coverage", [False, True])
+def test_wide_window_m_step_matches_oracle(coverage):
+    st = synth.make_store(50_000, 30_000, seed=177, coverage=coverage)      # sparse: the wide cap's home ground
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    rng = np.random.default_rng(11)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, window_cap=WIDE) as d:
+        for trial in range(3):
+            theta = rng.lognormal(0, 2, size=st.n_txps)
+            theta[rng.random(st.n_txps) < 0.1] = 0.0
+            assert_counts_close(d.m_step(theta), c_oracle.m_step(o, theta), st.n_reads, st.n_txps, 1e-10,
+                                f"wide m_step trial {trial}")
+        w = rng.poisson(1.0, size=st.n_reads).astype(np.uint32)
+        theta = np.full(st.n_txps, st.n_reads / st.n_txps)
+        assert_counts_close(d.m_step(theta, w), c_oracle.m_step(o, theta, row_w=w), st.n_reads, st.n_txps, 1e-10,
+                            "wide weighted m_step")
+
+
+@pytest.mark.parametrize("shape", ["sparse", "dense", "coverage"])
+@pytest.mark.parametrize("gate", [50, 1])
+def test_wide_window_em_matches_oracle(shape, gate):
+    if shape == "sparse":
+        st = synth.make_store(120_000, 100_000, seed=178)
+    elif shape == "dense":
+        st = synth.make_store(200_000, 12_000, seed=78)
+    else:
+        st = synth.make_store(80_000, 50_000, seed=179, coverage=True)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    want, wi = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=gate)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, window_cap=WIDE) as d:
+        got, gi = d.em_run(None, 1000, 1e-3, gate)
+        narrow = DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, window_cap=512)
+        try:
+            ncnt, ni = narrow.em_run(None, 1000, 1e-3, gate)
+        finally:
+            narrow.close()
+    assert abs(gi.niter - wi.niter) <= 1
+    assert_counts_close(got, want, st.n_reads, st.n_txps, RTOL if gi.niter != wi.niter else 1e-8, f"wide em {shape}")
+    if ni.niter == gi.niter:   # the two window caps are two layouts of the same sums
+        assert_counts_close(got, ncnt, st.n_reads, st.n_txps, 1e-8, "wide vs narrow")
+    assert abs(got.sum() - st.n_reads) < 1e-6 * st.n_reads
+
+
+def test_wide_window_injected_bootstrap_matches_oracle():
+    st = synth.make_store(60_000, 45_000, seed=180)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    rng = np.random.default_rng(5)
+    W = np.stack([np.bincount(rng.integers(0, st.n_reads, st.n_reads), minlength=st.n_reads)
+                  for _ in range(3)]).astype(np.uint32)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps, window_cap=WIDE) as d:
+        out, infos = d.bootstrap(3, row_w_all=W, max_iter=300, conv_thresh=1e-3)
+    for b in range(3):
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=300, conv_thresh=1e-3)
+        assert abs(infos[b].niter - wi.niter) <= 1
+        assert_counts_close(out[b], want, st.n_reads, st.n_txps, RTOL if infos[b].niter != wi.niter else 1e-8,
+                            f"wide bootstrap {b}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_wide_window_fuzz_random_shapes_match_oracle(seed):
+    rng = np.random.default_rng(9100 + seed)
+    R = int(rng.choice([1, 33, 900, 25_000, 90_000]))
+    T = int(rng.choice([1, 7, 400, 5_000, 120_000]))
+    maxk = int(rng.choice([1, 5, 16, 60]))
+    lens = rng.integers(0, maxk + 1, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    spread = int(rng.choice([1, 8, 300, max(T, 1)]))
+    tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
+    cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 3 == 0 else None
+    o = c_oracle.Store(rp, tid, p, cov, T)
+    want, wi = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3)
+    with DeviceStore(rp, tid, p, cov, T, window_cap=WIDE) as d:
+        got, gi = d.em_run(None, 200, 1e-3, 50)
+    what = f"wide fuzz seed {seed}: R={R} T={T} maxk={maxk} spread={spread} cov={cov is not None}"
+    assert abs(gi.niter - wi.niter) <= 1, what
+    assert_counts_close(got, want, max(R, 1), T, RTOL if gi.niter != wi.niter else 1e-8, what)
+
+
+@pytest.mark.timeout(1500)
+def test_c5_slice_per_cell_batch_matches_per_cell_oracle():
+    """BASELINE configs[4] at size: a slice of the single-cell workload -- 64 cells x 50 k reads each,
+    T = 60 k (3.2 M reads over 3.84 M virtual transcripts => the store picks the wide window cap by
+    itself and the fused fold finishes each pass) -- every cell against its own serial oracle run
+    (single_cell.rs:139-160: em::em per cell, init None, gate 50; em.rs:212)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_cells, per_cell, T = 64, 50_000, 60_000
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, per_cell, T, seed=31)
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=1000, convergence_thresh=1e-3)
+
+    def oracle_cell(c):
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        o = c_oracle.Store(row_ptr[r0:r1 + 1] - row_ptr[r0], tid[a0:a1], p[a0:a1], None, T)
+        return c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=50)
+
+    import os
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:   # ctypes releases the GIL
+        wants = list(ex.map(oracle_cell, range(n_cells)))
+    niters = set()
+    for c in range(n_cells):
+        want, wi = wants[c]
+        assert abs(infos[c].niter - wi.niter) <= 1, (c, infos[c], wi)
+        assert_counts_close(out[c], want, per_cell, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"cell {c}")
+        assert abs(out[c].sum() - per_cell) < 1e-6 * per_cell
+        niters.add(wi.niter)
+    assert len(niters) > 4      # the cells really stop at different iterations
+
+
+def test_stopping_rule_kernel_under_stress():
+    """k_reldiff_swap_clear elects the workgroup that takes the stopping decision (em.rs:194-218) with
+    two device-scope atomics per workgroup (running maximum, then a ticket) ordered by a counted wait
+    instead of a fence.  Hook of the test-only library: > 10^5 launches over grids of 1 .. 64
+    workgroups, every launch with a planted, exactly representable maximum at a pseudo-random place;
+    the decision workgroup's view of the maximum must equal it bit for bit every single time."""
+    import ctypes as C
+    from oarfish_amd import _lib
+    L = _lib.testing_lib()
+    total = 0
+    for T, n in ((1, 2_000), (900, 10_000), (5_000, 20_000), (33_000, 30_000), (70_000, 30_000), (200_000, 20_000),
+                 (1_500_000, 3_000)):
+        out = np.zeros(n)
+        rc = L.oem_test_reldiff_stress(T, n, 1234 + T, 0, out.ctypes.data)
+        assert rc == 0, L.oem_last_error()
+        want = 0.75 + np.arange(n) / 1048576.0
+        bad = np.nonzero(out != want)[0]
+        assert len(bad) == 0, f"T={T}: {len(bad)} of {n} launches saw a stale maximum, first at launch {bad[:5]}: {out[bad[:5]]}"
+        total += n
+    assert total > 100_000
