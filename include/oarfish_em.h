@@ -104,7 +104,7 @@ void oem_store_destroy(oem_store *store);
 /* Tuning switches of a store (not part of the reference's semantics; results are
  * unchanged up to floating-point summation order). */
 typedef enum {
-    OEM_OPT_BATCH_BOOTSTRAP = 1, /* value 1 (default): oem_bootstrap runs 2 replicates per pass over the
+    OEM_OPT_BATCH_BOOTSTRAP = 1, /* value 1 (default): oem_bootstrap runs 8 replicates per pass over the
                                     matrix when it can (f32 weights, multiplicities < 256); 0: one per pass */
     OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2 /* value b0 (default 0): replicate k of the next oem_bootstrap calls
                                     draws the device resample of global replica b0 + k.  Lets N processes
@@ -323,6 +323,15 @@ int oem_time_m_step(oem_store *store, uint32_t n_launches, float *out_avg_ms);
  * em.rs:181-207) from the uniform init with no convergence exit, timed with
  * HIP events on the store's stream; out_ms = total milliseconds. */
 int oem_time_em_iters(oem_store *store, uint32_t n_iters, float *out_ms);
+
+/* Run `n_passes` batched bootstrap passes (tile + fold + rel-diff kernels of oem_bootstrap's
+ * rolling batch) with every slot running its own device-drawn resample and no slot ever stopping,
+ * timed with HIP events on the store's stream.  out_avg_ms = milliseconds per batched pass;
+ * out_slots = replicates served by one pass; out_algorithmic_bytes = SURVEY.md section 8d's bytes
+ * of one batched pass (matrix once, row weights + theta/counts per replicate).  OEM_ERR_STATE when
+ * the store runs its bootstraps one per pass (f64 weights, wide windows, no tiled layout). */
+int oem_time_bootstrap_passes(oem_store *store, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
+                              uint64_t *out_algorithmic_bytes);
 
 #ifdef __cplusplus
 }

@@ -227,22 +227,39 @@ int ensure_batch(oem_store *s)
     OEM_TRY(dev_alloc(&b.out, T * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.queue, (size_t)s->tiled.n_remote * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
-    OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 4, &s->hbm_bytes));
-    OEM_TRY(dev_alloc(&b.row_w_all, (size_t)s->csr.n_reads * kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 16, &s->hbm_bytes));
+    OEM_HIP(hipMemsetAsync(b.row_w, 0, (size_t)s->tiled.n_rows * kBatch + 16, s->stream));
     OEM_TRY(dev_alloc(&b.overflow, 1, &s->hbm_bytes));
     OEM_HIP(hipHostMalloc((void **)&b.h_state, sizeof(BatchState) * kBatch, hipHostMallocDefault));
     OEM_HIP(hipHostMalloc((void **)&b.h_out, sizeof(double) * T * kBatch, hipHostMallocDefault));
     return OEM_OK;
 }
 
+// The batch kernel takes f32 weights, narrow windows and byte multiplicities.
 bool can_batch(const oem_store *s)
 {
-    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0 && s->tiled.win_cap <= kWin; // batch kernel: narrow windows
+    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0 && s->tiled.win_cap <= kWin;
+}
+
+// A decision that selects which collectives a row-sharded run issues must be the same on every
+// rank: flag = 1 on any rank => 1 on all (one tiny all-reduce; a no-op without a communicator).
+int agree_any(oem_store *s, bool *flag)
+{
+    if (!comm_exchanges(s->comm)) return OEM_OK;
+    double *d = s->cnt; // scratch: the count vector is rebuilt by every run
+    const double v = *flag ? 1.0 : 0.0;
+    OEM_HIP(hipMemcpyAsync(d, &v, sizeof(double), hipMemcpyHostToDevice, s->stream));
+    OEM_TRY(comm_allreduce_sum_f64(s->comm, d, d, 1, s->stream));
+    double r = 0.0;
+    OEM_HIP(hipMemcpyAsync(&r, d, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    *flag = r != 0.0;
+    return OEM_OK;
 }
 
 // Rolling batch: kBatch slots share every pass over the matrix; a slot whose replicate has finished
-// is handed the next replicate at once, so both slots stay busy until the replicates run out (with
-// fixed pairs the pass count of a pair is the larger of the two, and every pair pays its own set-up).
+// is handed the next replicate at once, so the slots stay busy until the replicates run out (with
+// fixed groups the pass count of a group is its largest, and every group pays its own set-up).
 // Replicates whose multiplicities do not fit a byte are returned in `fallback` (one-per-pass path).
 int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all, const double *init,
                           uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos,
@@ -262,7 +279,6 @@ int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const ui
     const bool sharded = comm_exchanges(s->comm);
     int slot_rep[kBatch];
     uint32_t next = 0;
-    OEM_HIP(hipMemsetAsync(bb.row_w_all, 0, sizeof(uint32_t) * R * kBatch, s->stream));
     OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
     for (int k = 0; k < kBatch; ++k) {
         slot_rep[k] = -1;
@@ -273,25 +289,24 @@ int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const ui
 
     // hands slot k the next replicate that fits (or leaves it idle when none is left)
     auto load = [&](int k) -> int {
-        uint32_t *dst = bb.row_w_all + (size_t)k * R;
         while (next < n_boot) {
             const uint32_t rep = next++;
             if (row_w_all) {
-                OEM_HIP(hipMemcpyAsync(dst, row_w_all + (size_t)rep * R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, s->stream));
+                OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (size_t)rep * R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, s->stream));
             } else {
-                OEM_TRY(launch_bootstrap_weights(s, dst, R, s->global_row_offset, s->global_n_reads, seed,
+                OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset, s->global_n_reads, seed,
                                                  s->bootstrap_first_replica + rep)); // em.rs:274-276
             }
             OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
-            OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
+            OEM_TRY(launch_batch_pack_row_w(s, s->d_row_w, bb, (uint32_t)k, bb.overflow));
             uint32_t h_overflow = 0;
             OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
             OEM_HIP(hipStreamSynchronize(s->stream));
-            if (h_overflow) { // a multiplicity >= 256: this replicate goes to the one-per-pass path
+            bool over = h_overflow != 0;
+            OEM_TRY(agree_any(s, &over)); // row shards: every rank must route the replicate the same way
+            if (over) { // a multiplicity >= 256: this replicate goes to the one-per-pass path
                 fallback->push_back(rep);
-                OEM_HIP(hipMemsetAsync(dst, 0, sizeof(uint32_t) * R, s->stream));
-                OEM_TRY(launch_batch_pack_row_w(s, bb.row_w_all, bb, bb.overflow));
-                continue;
+                continue; // (the slot's byte column is rewritten by the next replicate it is handed)
             }
             OEM_TRY(launch_batch_reset_slot(s, bb, d_init, avg, (uint32_t)k));
             std::memset(&bb.h_state[k], 0, sizeof(BatchState));
@@ -358,7 +373,7 @@ void free_store(oem_store *s)
     {
         oem::BatchBuffers &b = s->batch;
         hipFree(b.theta); hipFree(b.cnt); hipFree(b.out); hipFree(b.queue); hipFree(b.state);
-        hipFree(b.row_w); hipFree(b.row_w_all); hipFree(b.overflow);
+        hipFree(b.row_w); hipFree(b.overflow);
         if (b.h_state) hipHostFree(b.h_state);
         if (b.h_out) hipHostFree(b.h_out);
     }
@@ -809,7 +824,9 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
     const uint64_t R = s->csr.n_reads;
     // the replicates that run one per pass: all of them, or those the rolling batch hands back
     std::vector<uint32_t> single;
-    if (s->batch_bootstrap && can_batch(s) && max_iter >= 1 && n_boot >= 2) {
+    bool no_batch = !(s->batch_bootstrap && can_batch(s));
+    OEM_TRY(agree_any(s, &no_batch)); // row shards tile their own blocks: all ranks batch, or none does
+    if (!no_batch && max_iter >= 1 && n_boot >= 2) {
         OEM_TRY(run_bootstrap_rolling(s, n_boot, seed, row_w_all, init_abundances, max_iter, conv_thresh, out, infos,
                                       &single));
     } else {
@@ -1137,5 +1154,57 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *out_ms = ms;
+    return OEM_OK;
+}
+
+extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
+                                         uint64_t *out_algorithmic_bytes)
+{
+    if (!s || !out_avg_ms || n_passes == 0) return fail(OEM_ERR_ARG, "oem_time_bootstrap_passes: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    if (!can_batch(s)) return fail(OEM_ERR_STATE, "oem_time_bootstrap_passes: this store runs its bootstraps one per pass");
+    OEM_TRY(ensure_row_w(s));
+    OEM_TRY(ensure_batch(s));
+    BatchBuffers &bb = s->batch;
+    const uint32_t T = s->csr.n_txps;
+    const uint64_t R = s->csr.n_reads;
+    const double avg = (double)s->global_n_reads / (double)T;
+    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
+    for (int k = 0; k < kBatch; ++k) { // every slot RUNNING on its own device-drawn resample
+        OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset, s->global_n_reads, 0x7e57ull, (uint32_t)k));
+        OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
+        OEM_TRY(launch_batch_pack_row_w(s, s->d_row_w, bb, (uint32_t)k, bb.overflow));
+        OEM_TRY(launch_batch_reset_slot(s, bb, nullptr, avg, (uint32_t)k));
+        std::memset(&bb.h_state[k], 0, sizeof(BatchState));
+        bb.h_state[k].phase = kPhaseRunning;
+    }
+    OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
+    EmParams p{T, 0xffffffffu, 0xffffffffu, -1.0}; // no slot ever stops (SURVEY.md 8a note 3)
+    hipEvent_t e0, e1;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    OEM_TRY(launch_batch_pass(s, bb)); // one untimed pass
+    OEM_TRY(launch_batch_reldiff(s, bb, p));
+    OEM_HIP(hipEventRecord(e0, s->stream));
+    for (uint32_t i = 0; i < n_passes; ++i) {
+        OEM_TRY(launch_batch_pass(s, bb));
+        OEM_TRY(launch_batch_reldiff(s, bb, p));
+    }
+    OEM_HIP(hipEventRecord(e1, s->stream));
+    OEM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *out_avg_ms = ms / (float)n_passes;
+    if (out_slots) *out_slots = kBatch;
+    if (out_algorithmic_bytes) {
+        // the matrix once per batched pass (nnz * 8 + row pointers), and per replicate the
+        // row weights (R * 4) and theta read / counts written once per transcript (2 * T * 8)
+        const DeviceCsr &m = s->csr;
+        *out_algorithmic_bytes = m.nnz * 8 + (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) +
+                                 (uint64_t)kBatch * (m.n_reads * 4 + 2ull * m.n_txps * 8);
+    }
     return OEM_OK;
 }

@@ -1,19 +1,28 @@
 // oem_batch_kernels.hip -- kBatch bootstrap replicates per pass over the resident matrix.
 //
 // em::bootstrap (em.rs:292-314) runs num_boot independent resampled EMs, each a serial
-// do_em over random_sampling_iter (em.rs:273-290).  Every replicate streams the whole
-// store again.  Here kBatch replicates share one pass over the tiled matrix: the
-// weights w and window codes are read once and folded against kBatch abundance
-// vectors (theta laid out [transcript][replicate], so one 32-byte access serves all
-// replicates of a transcript), each read scaled by its per-replicate multiplicity
-// c_ib ~ Multinomial(R; 1/R) (bootstrap.rs:7-16).
+// do_em over random_sampling_iter (em.rs:273-290); every replicate streams the whole store
+// again.  Here kBatch = 8 replicates ("slots") share one pass over the tiled matrix.
 //
-// Every replicate keeps its own loop state on the device and walks the reference's
-// state machine by itself: RUNNING -(stopping rule em.rs:212 / max_iter em.rs:181)->
-// FINAL (theta < 1e-5 read as 0, em.rs:238-242; one more pass, em.rs:245-252) ->
-// FINISHED (counts parked in `out`, replicate ignored from then on).
-#include <cstdlib>
-
+// What amortises and what does not.  The matrix streams (weights, window codes, remote
+// records: ~0.65 GB at 10 M reads) and the L2 requests of the remote theta gathers are paid
+// once per pass whatever the number of slots: theta is laid out [transcript][slot], so the
+// kEB = 4 slots of an epoch sit in one 32-byte piece of a 64-byte line.  The per-slot work
+// (LDS traffic of the local alignments, 8 bytes of queue per remote alignment) is not shared.
+//
+// k_em_tile_e: one workgroup per tile, the tile's matrix data loaded ONCE into registers,
+// then kE "epochs" of kEB = 4 slots each run over it: per epoch the theta window, the count
+// window and the denominators of 4 slots live in LDS (64 KiB per workgroup => two workgroups
+// per CU overlap one tile's memory phases with the other's LDS phases), one read per lane as
+// in k_em_tile (oem_tile_kernels.hip).  Inside an epoch lane l works on slot (j + l) mod 4 at
+// step j ("rotated" slot order): lanes that add into the same transcript in the same
+// instruction hit four different addresses, the job the four interleaved count-window copies
+// do in k_em_tile, with no extra LDS.
+//
+// Every slot keeps its own loop state on the device and walks the reference's state machine
+// by itself: RUNNING -(stopping rule em.rs:212 / max_iter em.rs:181)-> FINAL (theta < 1e-5
+// read as 0, em.rs:238-242; one more pass, em.rs:245-252) -> FINISHED (counts parked in
+// `out`, slot ignored from then on, handed the next replicate by the host).
 #include "oem_internal.h"
 
 namespace oem {
@@ -21,12 +30,26 @@ namespace oem {
 namespace {
 
 constexpr int kB = kBatch;
-constexpr int kBCh = 8;     // alignments per read kept in registers
+constexpr int kEB = 4;             // slots per epoch
+constexpr int kE = kB / kEB;       // epochs per pass
+constexpr int kBCh = 8;            // local alignments per read kept in registers
+constexpr int kTileThreadsE = 512; // 8 wavefronts, 2 slices each
+constexpr int kRemE = 3;           // remote alignments per thread kept in registers
 constexpr int kFoldThreadsB = 1024;
+static_assert(kB % kEB == 0 && kE >= 1, "kBatch must be a multiple of the epoch width");
+static_assert((kB & (kB - 1)) == 0 && kB <= 16, "row multiplicities are packed kB bytes per read");
 
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_f64
+}
+__device__ __forceinline__ double lds_ld_b(const double *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ double *lds_at_b(double *base, uint32_t byte_off)
+{
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
 struct SliceRegsB {
@@ -57,14 +80,17 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restr
             r.c[g] = 0u;
         }
     }
+    // the second element of the last pair of an odd-width slice belongs to the next read
+#pragma unroll
+    for (int k = 1; k < kBCh; k += 2)
+        if ((uint32_t)k >= width) r.w[k] = 0.f;
 }
 
-// Same structure as k_em_tile (oem_tile_kernels.hip): one workgroup per tile, one read per
-// lane, slices prefetched one ahead, operands landed with one counted wait, count window in
-// kCopies interleaved copies -- with every LDS / queue / theta entity carrying kB replicates.
-// Window entry (c, b, copy p) lives at ((c * kB + b) * kCopies + p).
-template <int kThreads, int kRem, int kCopies, int kMinWaves, bool kNT>
-__global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
+// LDS layouts of one epoch (b = slot inside the epoch, c = window entry, r = read of the tile):
+//   theta_l, cnt_l : [c][b]  byte (c * kEB + b) * 8 = code * kEB + b * 8   (code = 8 c, as stored)
+//   den_l          : [b][r]  remote part of the denominators, then c_ib / denom_ib
+template <bool kNT>
+__global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const float *__restrict__ w, const uint32_t *__restrict__ r_tid, const float *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
@@ -72,8 +98,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
 {
-    uint32_t act = 0; // replicates that still take part in this pass (RUNNING or FINAL)
-    uint32_t fin = 0; // replicates on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
+    uint32_t act = 0; // slots that take part in this pass (RUNNING or FINAL)
+    uint32_t fin = 0; // slots on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
         const uint32_t ph = st[b].phase;
@@ -81,21 +107,17 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
         fin |= (ph == kPhaseFinal) ? (1u << b) : 0u;
     }
     if (!act) return;
-    auto th = [&](double v, int b) -> double {
-        return (((fin >> b) & 1u) && v < OEM_MIN_READ_THRESH) ? 0.0 : v;
-    };
 
-    __shared__ double theta_l[kWin * kB];
-    __shared__ double cnt_l[kWin * kB * kCopies];
-    __shared__ double den_l[kTileRows * kB];
+    __shared__ double theta_l[kWin * kEB];
+    __shared__ double cnt_l[kWin * kEB];
+    __shared__ double den_l[kEB * kTileRows];
 
-    constexpr uint32_t kWaves = kThreads / 64;
+    constexpr uint32_t kWaves = kTileThreadsE / 64;
     constexpr uint32_t kPerWave = kTileSlices / kWaves;
     const TileDesc td = tiles[blockIdx.x];
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);
-    const uint32_t copy = lane % kCopies;
 
     uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
     {
@@ -113,156 +135,194 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void k_em_tile_b(
         }
     }
 
-    // remote alignments of this thread: x[b] = theta[t][b] * w (one 16-byte access serves both replicates)
-    double rx[kRem][kB];
-    uint32_t rrow[kRem], rslot[kRem];
-    {
-        uint32_t rt[kRem];
-        float rw[kRem];
+    // ---- the tile's matrix data, loaded once and kept in registers over all epochs ----------
+    SliceRegsB R[kPerWave];
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) {
-            const uint32_t i = tx + k * kThreads;
-            rt[k] = 0; rw[k] = 0.f; rrow[k] = 0; rslot[k] = 0;
-            if (i < td.remote_cnt) {
-                const uint32_t o = td.remote_begin + i;
-                rt[k] = ld_stream_b<kNT>(&r_tid[o]);
-                rw[k] = ld_stream_b<kNT>(&r_w[o]);
-                rrow[k] = ld_stream_b<kNT>(&r_row[o]);
-                rslot[k] = ld_stream_b<kNT>(&r_slot[o]);
+    for (uint32_t q = 0; q < kPerWave; ++q)
+        load_slice_b<kNT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+    uint32_t rt[kRemE], rrow[kRemE], rslot[kRemE];
+    float rw[kRemE];
+#pragma unroll
+    for (int k = 0; k < kRemE; ++k) {
+        const uint32_t i = tx + k * kTileThreadsE;
+        rt[k] = 0; rw[k] = 0.f; rrow[k] = 0; rslot[k] = 0;
+        if (i < td.remote_cnt) {
+            const uint32_t o = td.remote_begin + i;
+            rt[k] = ld_stream_b<kNT>(&r_tid[o]);
+            rw[k] = ld_stream_b<kNT>(&r_w[o]);
+            rrow[k] = ld_stream_b<kNT>(&r_row[o]);
+            rslot[k] = ld_stream_b<kNT>(&r_slot[o]);
+        }
+    }
+    // slot of this lane at step j of an epoch: (j + lane) mod kEB
+    uint32_t rot8[kEB]; // byte offset of that slot inside a [c][b] window entry
+#pragma unroll
+    for (int j = 0; j < kEB; ++j) rot8[j] = ((j + lane) & (kEB - 1)) * 8u;
+
+#pragma unroll 1
+    for (int e = 0; e < kE; ++e) {
+        const uint32_t act_e = (act >> (e * kEB)) & ((1u << kEB) - 1u);
+        const uint32_t fin_e = (fin >> (e * kEB)) & ((1u << kEB) - 1u);
+        if (!act_e) continue; // no slot of this epoch is running (wave-uniform)
+        auto th = [&](double v, uint32_t b) -> double {
+            return (((fin_e >> b) & 1u) && v < OEM_MIN_READ_THRESH) ? 0.0 : v;
+        };
+        const size_t eoff = (size_t)e * kEB; // first slot of the epoch
+
+        // multiplicities of this wavefront's reads, one byte per slot
+        uint32_t mult[kPerWave];
+#pragma unroll
+        for (uint32_t q = 0; q < kPerWave; ++q) {
+            const uint32_t rl = (wave + kWaves * q) * 64 + lane;
+            mult[q] = rl < td.n_rows ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff) : 0u;
+        }
+        // remote alignments: x[b] = theta[t][b] * w; the epoch's four slots are one 32-byte piece
+        double rx[kRemE][kEB];
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k) {
+            const double *tp = theta + (size_t)rt[k] * kB + eoff;
+#pragma unroll
+            for (int b = 0; b < kEB; ++b) rx[k][b] = th(tp[b], b) * (double)rw[k];
+        }
+        for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE)
+            theta_l[i] = th(theta[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], i % kEB);
+        for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) cnt_l[i] = 0.0;
+        for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreadsE) {
+#pragma unroll
+            for (int b = 0; b < kEB; ++b) den_l[b * kTileRows + i] = 0.0;
+        }
+        __syncthreads();
+
+        // ---- remote phase A: denominators ------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k)
+            if (tx + k * kTileThreadsE < td.remote_cnt) {
+#pragma unroll
+                for (int b = 0; b < kEB; ++b) lds_add(&den_l[b * kTileRows + rrow[k]], rx[k][b]);
+            }
+        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // overflow: park x in the queue
+            const uint32_t o = td.remote_begin + i;
+            const double *tp = theta + (size_t)r_tid[o] * kB + eoff;
+            const double wv = (double)r_w[o];
+#pragma unroll
+            for (int b = 0; b < kEB; ++b) {
+                const double x = th(tp[b], b) * wv;
+                queue[(eoff + b) * n_remote + r_slot[o]] = x;
+                lds_add(&den_l[b * kTileRows + r_row[o]], x);
             }
         }
-#pragma unroll
-        for (int k = 0; k < kRem; ++k) {
-#pragma unroll
-            for (int b = 0; b < kB; ++b) rx[k][b] = th(theta[(size_t)rt[k] * kB + b], b) * (double)rw[k];
-        }
-    }
-    constexpr uint32_t kSets = kPerWave > 1 ? 2 : 1;
-    SliceRegsB R[kSets];
-    load_slice_b<kNT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+        __syncthreads();
 
-    for (uint32_t i = tx; i < td.win_len * kB; i += kThreads) theta_l[i] = th(theta[(size_t)td.lo * kB + i], i % kB);
-    for (uint32_t i = tx; i < td.win_len * kB * kCopies; i += kThreads) cnt_l[i] = 0.0;
-    for (uint32_t i = tx; i < td.n_slices * 64 * kB; i += kThreads) den_l[i] = 0.0;
-    __syncthreads();
-
-    // remote phase A: denominators
+        // ---- local alignments: one read per lane, slots in rotated order ---------------------
+        // (one slice at a time, not interleaved: the slices' operands are already in registers and the
+        // second pass recomputes its LDS addresses, which keeps the kernel inside 128 VGPRs)
+#pragma unroll 1
+        for (uint32_t q = 0; q < kPerWave; ++q) {
+            const uint32_t s = wave + kWaves * q;
+            if (s >= td.n_slices) continue;
+            SliceRegsB cur;
+            uint32_t width = wid[0], mq = mult[0], wo = woff[0], co = coff[0];
 #pragma unroll
-    for (int k = 0; k < kRem; ++k)
-        if (tx + k * kThreads < td.remote_cnt) {
+            for (int k = 0; k < kBCh; ++k) cur.w[k] = R[0].w[k];
 #pragma unroll
-            for (int b = 0; b < kB; ++b) lds_add(&den_l[rrow[k] * kB + b], rx[k][b]);
-        }
-    for (uint32_t i = tx + kRem * kThreads; i < td.remote_cnt; i += kThreads) { // overflow: park in the queue
-        const uint32_t o = td.remote_begin + i;
-        const uint32_t t = r_tid[o];
-        const double wv = (double)r_w[o];
+            for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[0].c[k];
 #pragma unroll
-        for (int b = 0; b < kB; ++b) {
-            const double x = th(theta[(size_t)t * kB + b], b) * wv;
-            queue[(size_t)b * n_remote + r_slot[o]] = x;
-            lds_add(&den_l[r_row[o] * kB + b], x);
-        }
-    }
-    __syncthreads();
-
-    // local alignments
+            for (uint32_t qq = 1; qq < kPerWave; ++qq)
+                if (q == qq) { // wave-uniform
+                    width = wid[qq]; mq = mult[qq]; wo = woff[qq]; co = coff[qq];
 #pragma unroll
-    for (uint32_t q = 0; q < kPerWave; ++q) {
-        const uint32_t s = wave + kWaves * q;
-        if (q + 1 < kPerWave)
-            load_slice_b<kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
-                         wid[q + 1]);
-        if (s >= td.n_slices) continue;
-        const SliceRegsB &cur = R[q % kSets];
-        // land this slice's operands with one counted wait (the next slice's loads stay in flight)
+                    for (int k = 0; k < kBCh; ++k) cur.w[k] = R[qq].w[k];
 #pragma unroll
-        for (int k = 0; k < kBCh; ++k) asm volatile("" ::"v"(cur.w[k]));
+                    for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[qq].c[k];
+                }
+            const uint32_t rl = s * 64 + lane;
+            const float *wbase = w + (size_t)wo * 64;
+            const uint32_t *cbase = codes + (size_t)co * 64;
+            double denom[kEB];
 #pragma unroll
-        for (int k = 0; k < kBCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
-        const uint32_t width = wid[q];
-        const uint32_t rl = s * 64 + lane;
-        const float *wbase = w + (size_t)woff[q] * 64;
-        const uint32_t *cbase = codes + (size_t)coff[q] * 64;
-        uint32_t mult = 0; // packed multiplicities of this read, one byte per replicate
-        if (rl < td.n_rows) {
-            const uint8_t *mp = row_w + (size_t)(td.row_base + rl) * kB;
-#pragma unroll
-            for (int b = 0; b < kB; ++b) mult |= (uint32_t)mp[b] << (8 * b);
-        }
-        double inv[kB];
-#pragma unroll
-        for (int b = 0; b < kB; ++b) {
-            double denom = den_l[rl * kB + b];
+            for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
 #pragma unroll
             for (int k = 0; k < kBCh; ++k) {
-                const uint32_t c = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) >> 3;
-                const double wk = (uint32_t)k < width ? (double)cur.w[k] : 0.0;
-                denom += theta_l[c * kB + b] * wk;                               // em.rs:111
-            }
-            for (uint32_t j = kBCh; j < width; ++j) {
-                const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-                const uint32_t c = ((j & 1) ? (cc >> 16) : (cc & 0xffffu)) >> 3;
-                denom += theta_l[c * kB + b] * (double)wbase[j * 64 + lane];
-            }
-            const double scale = (double)((mult >> (8 * b)) & 0xffu);
-            inv[b] = ((act >> b) & 1u) && denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0; // em.rs:115
-            den_l[rl * kB + b] = inv[b];
-        }
-#pragma unroll
-        for (int k = 0; k < kBCh; ++k) {
-            if ((uint32_t)k < width) {
-                const uint32_t c = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) >> 3;
+                const uint32_t off = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) * kEB;
                 const double wk = (double)cur.w[k];
 #pragma unroll
-                for (int b = 0; b < kB; ++b) {
-                    const double v = theta_l[c * kB + b] * wk * inv[b];
-                    if (v != 0.0) lds_add(&cnt_l[(c * kB + b) * kCopies + copy], v); // em.rs:128-129
+                for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
+                if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
+            }
+            for (uint32_t i = kBCh; i < width; ++i) { // reads with more than kBCh local alignments
+                const uint32_t cc = cbase[(i >> 1) * 64 + lane];
+                const uint32_t off = ((i & 1) ? (cc >> 16) : (cc & 0xffffu)) * kEB;
+                const double wk = (double)wbase[i * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
+            }
+            double inv[kEB];
+#pragma unroll
+            for (int j = 0; j < kEB; ++j) {
+                const uint32_t b = rot8[j] >> 3;
+                const double scale = (double)((mq >> (8 * b)) & 0xffu);
+                inv[j] = (((act_e >> b) & 1u) && denom[j] > OEM_EM_DENOM_THRESH) ? scale / denom[j] : 0.0; // em.rs:115
+                den_l[b * kTileRows + rl] = inv[j];
+            }
+            // the second pass derives its addresses and weights again from the packed operands
+#pragma unroll
+            for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(cur.w[k]));
+#pragma unroll
+            for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(cur.c[k]));
+#pragma unroll
+            for (int k = 0; k < kBCh; ++k) {
+                if ((uint32_t)k < width) { // wave-uniform
+                    const uint32_t off = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) * kEB;
+                    const double wk = (double)cur.w[k];
+#pragma unroll
+                    for (int j = 0; j < kEB; ++j) {
+                        const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                        if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (uint32_t i = kBCh; i < width; ++i) {
+                const uint32_t cc = cbase[(i >> 1) * 64 + lane];
+                const uint32_t off = ((i & 1) ? (cc >> 16) : (cc & 0xffffu)) * kEB;
+                const double wk = (double)wbase[i * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < kEB; ++j) {
+                    const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                    if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
                 }
             }
         }
-        for (uint32_t j = kBCh; j < width; ++j) {
-            const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-            const uint32_t c = ((j & 1) ? (cc >> 16) : (cc & 0xffffu)) >> 3;
-            const double wk = (double)wbase[j * 64 + lane];
+        __syncthreads();
+
+        // ---- remote phase B: queue[slot][.] <- x_b * (c_ib / denom_ib) -------------------------
 #pragma unroll
-            for (int b = 0; b < kB; ++b) {
-                const double v = theta_l[c * kB + b] * wk * inv[b];
-                if (v != 0.0) lds_add(&cnt_l[(c * kB + b) * kCopies + copy], v);
+        for (int k = 0; k < kRemE; ++k) {
+            if (tx + k * kTileThreadsE < td.remote_cnt) {
+#pragma unroll
+                for (int b = 0; b < kEB; ++b)
+                    queue[(eoff + b) * n_remote + rslot[k]] = rx[k][b] * den_l[b * kTileRows + rrow[k]];
             }
         }
-    }
-    __syncthreads();
-
-    // remote phase B: queue[b][slot] <- x_b * (c_ib / denom_ib)
+        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
+            const uint32_t o = td.remote_begin + i;
 #pragma unroll
-    for (int k = 0; k < kRem; ++k) {
-        const uint32_t i = tx + k * kThreads;
-        if (i < td.remote_cnt) {
-#pragma unroll
-            for (int b = 0; b < kB; ++b)
-                queue[(size_t)b * n_remote + rslot[k]] = rx[k][b] * den_l[rrow[k] * kB + b];
+            for (int b = 0; b < kEB; ++b) {
+                const size_t qi = (eoff + b) * n_remote + r_slot[o];
+                queue[qi] = queue[qi] * den_l[b * kTileRows + r_row[o]];
+            }
         }
-    }
-    for (uint32_t i = tx + kRem * kThreads; i < td.remote_cnt; i += kThreads) {
-        const uint32_t o = td.remote_begin + i;
-#pragma unroll
-        for (int b = 0; b < kB; ++b) {
-            const size_t qi = (size_t)b * n_remote + r_slot[o];
-            queue[qi] = queue[qi] * den_l[r_row[o] * kB + b];
+        // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b] --------------------------
+        for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) {
+            const double v = cnt_l[i];
+            if (v != 0.0) unsafeAtomicAdd(&cnt[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], v);
         }
-    }
-    // flush: the window is contiguous in [T][kB]
-    for (uint32_t i = tx; i < td.win_len * kB; i += kThreads) {
-        double v = 0.0;
-#pragma unroll
-        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
-        if (v != 0.0) unsafeAtomicAdd(&cnt[(size_t)td.lo * kB + i], v);
+        if (e + 1 < kE) __syncthreads(); // the next epoch re-initialises the windows
     }
 }
 
-// one workgroup per (replicate, bucket, group): streams queue[b][range] into an LDS window and
-// flushes it into cnt2[b][.] (replicate-major, so the flush is line-coalesced)
+// one workgroup per (slot, bucket, group): streams queue[slot][range] into an LDS window and
+// flushes it into cnt2[slot][.] (slot-major, so the flush is line-coalesced)
 __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
     const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue, uint64_t n_remote,
     const uint16_t *__restrict__ q_dst, double *__restrict__ cnt2 /* [kB][T] */,
@@ -306,38 +366,38 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
     }
 }
 
-// rel-diff / swap / clear / state machine for kB replicates (em.rs:194-218, :238-254)
+// rel-diff / swap / clear / state machine for kB slots (em.rs:194-218, :238-254)
 //   curr_b[t] = cnt[t][b] + cnt2[b][t]
 constexpr int kRelB = 1024; // as k_reldiff_swap_clear: few fat workgroups, the state-line atomics serialise
 __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
                                                    double *__restrict__ cnt2, double *__restrict__ out,
                                                    BatchState *st, EmParams p)
 {
-    uint32_t phase[kB];
-    uint32_t any = 0;
+    uint32_t running = 0, final_ = 0; // SGPR masks
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
-        phase[b] = st[b].phase;
-        any |= phase[b] != kPhaseFinished;
+        const uint32_t ph = st[b].phase;
+        running |= (ph == kPhaseRunning) ? (1u << b) : 0u;
+        final_ |= (ph == kPhaseFinal) ? (1u << b) : 0u;
     }
-    if (!any) return;
+    if (!(running | final_)) return;
     double rel[kB];
 #pragma unroll
     for (int b = 0; b < kB; ++b) rel[b] = 0.0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps; i += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
-            if (phase[b] == kPhaseFinished) continue;
+            if (!(((running | final_) >> b) & 1u)) continue;
             const size_t ia = (size_t)i * kB + b, ib = (size_t)b * p.n_txps + i;
             const double cc = cnt[ia] + cnt2[ib];
             cnt[ia] = 0.0;
             cnt2[ib] = 0.0;
-            if (phase[b] == kPhaseFinal) {
+            if ((final_ >> b) & 1u) {
                 out[ib] = cc;                               // em.rs:254
             } else {
                 const double pc = theta[ia];
                 if (pc > OEM_MIN_READ_THRESH) rel[b] = fmax(rel[b], (cc - pc) / pc); // em.rs:195-199
-                theta[ia] = cc;                             // em.rs:204 (zeroing of small values: below)
+                theta[ia] = cc;                             // em.rs:204 (zeroing of small values: k_em_tile_e reads them as 0)
             }
         }
     }
@@ -358,6 +418,7 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
             for (int i = 1; i < kRelB / 64; ++i) m = fmax(m, smax[i][b]);
             if (m > 0.0) atomicMax(&st[b].rel_bits, (unsigned long long)__double_as_longlong(m));
         }
+        // (ordering of the maxima against the ticket: see k_reldiff_swap_clear, oem_kernels.hip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t ticket = atomicAdd(&st[0].blocks_arrived, 1u);
         is_last = (ticket == gridDim.x - 1);
@@ -366,12 +427,12 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     if (is_last && threadIdx.x == 0) {
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
-            if (phase[b] == kPhaseFinished) continue;
-            if (phase[b] == kPhaseFinal) {
+            if ((final_ >> b) & 1u) {
                 st[b].n_passes += 1;
                 st[b].phase = kPhaseFinished;
                 continue;
             }
+            if (!((running >> b) & 1u)) continue;
             const unsigned long long bits =
                 __hip_atomic_load(&st[b].rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double rel_diff = __longlong_as_double((long long)bits);
@@ -404,22 +465,18 @@ __global__ __launch_bounds__(256) void k_reset_slot_b(double *__restrict__ theta
     }
 }
 
-// multiplicities of kB replicates, caller order u32 [kB][R] -> tile order u8 [rows][kB];
-// *overflow is set if a multiplicity does not fit a byte (the caller then falls back to the
-// one-replicate-per-pass path)
-__global__ __launch_bounds__(256) void k_pack_row_w_b(const uint32_t *__restrict__ row_w, uint64_t n_reads,
+// multiplicities of ONE slot, caller order u32 [R] -> its byte column of the tile-order table
+// u8 [rows][kB]; *overflow is set if a multiplicity does not fit a byte (the caller then runs that
+// replicate on the one-replicate-per-pass path)
+__global__ __launch_bounds__(256) void k_pack_row_w_b(const uint32_t *__restrict__ row_w,
                                                       const uint32_t *__restrict__ perm, uint64_t n_rows,
-                                                      uint8_t *__restrict__ out, uint32_t *overflow)
+                                                      uint8_t *__restrict__ out, uint32_t slot, uint32_t *overflow)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = perm[i];
-#pragma unroll
-        for (int b = 0; b < kB; ++b) {
-            const uint32_t c = row_w[(uint64_t)b * n_reads + r];
-            if (c > 255u) *overflow = 1u;
-            out[i * kB + b] = (uint8_t)(c & 0xffu);
-        }
+        const uint32_t c = row_w[perm[i]];
+        if (c > 255u) *overflow = 1u;
+        out[i * kB + slot] = (uint8_t)(c & 0xffu);
     }
 }
 
@@ -437,27 +494,16 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    const int variant = (int)knob("OEM_BATCH_VARIANT", 0); // testing build only
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * 6 + t.n_remote * 14;
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
-#define OEM_TILE_B_NT(TH, REM, NC, MW, NT)                                                                \
-    hipLaunchKernelGGL((k_em_tile_b<TH, REM, NC, MW, NT>), dim3(t.n_tiles), dim3(TH), 0, s->stream,         \
-                       t.tiles, t.codes, (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row,    \
-                       t.r_slot, bb.queue, t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
-#define OEM_TILE_B(TH, REM, NC, MW)                                                                       \
-    do {                                                                                                  \
-        if (nt) OEM_TILE_B_NT(TH, REM, NC, MW, true);                                                     \
-        else OEM_TILE_B_NT(TH, REM, NC, MW, false);                                                       \
-    } while (0)
-    switch (variant) {
-    case 1: OEM_TILE_B(256, 6, 4, 2); break;
-    case 2: OEM_TILE_B(512, 3, 2, 2); break;
-    case 3: OEM_TILE_B(512, 3, 4, 2); break;
-    case 4: OEM_TILE_B(256, 6, 1, 2); break;
-    default: OEM_TILE_B(256, 6, 2, 2); break;
-    }
-#undef OEM_TILE_B
-#undef OEM_TILE_B_NT
+    if (nt)
+        hipLaunchKernelGGL((k_em_tile_e<true>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, s->stream, t.tiles, t.codes,
+                           (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
+                           t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
+    else
+        hipLaunchKernelGGL((k_em_tile_e<false>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, s->stream, t.tiles, t.codes,
+                           (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
+                           t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);
@@ -478,7 +524,6 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
     const int grid = grid_for(p.n_txps, kRelB, 64);
     hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
-    // (a replicate on its FINAL pass reads theta < 1e-5 as 0 inside k_em_tile_b: em.rs:238-242)
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }
@@ -492,12 +537,13 @@ int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *
     return OEM_OK;
 }
 
-int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow)
+int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w, const BatchBuffers &bb, uint32_t slot,
+                            uint32_t *d_overflow)
 {
     const uint64_t n = s->tiled.n_rows;
     if (n == 0) return OEM_OK;
-    hipLaunchKernelGGL(k_pack_row_w_b, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s->stream, d_row_w_all,
-                       s->csr.n_reads, s->tiled.perm, n, bb.row_w, d_overflow);
+    hipLaunchKernelGGL(k_pack_row_w_b, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s->stream, d_row_w,
+                       s->tiled.perm, n, bb.row_w, slot, d_overflow);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

@@ -110,11 +110,11 @@ struct DeviceTiled {
 };
 
 // ---------------------------------------------------------------------------
-// Batched bootstrap: kBatch replicates share each pass over the matrix
-// (oem_batch_kernels.hip).  Per-replicate loop state, walked on the device:
+// Batched bootstrap: kBatch replicates ("slots") share each pass over the matrix
+// (oem_batch_kernels.hip).  Per-slot loop state, walked on the device:
 // RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
-constexpr int kBatch = 2;
+constexpr int kBatch = 8;
 enum : uint32_t { kPhaseRunning = 0, kPhaseFinal = 1, kPhaseFinished = 2 };
 
 struct BatchState {
@@ -137,8 +137,7 @@ struct BatchBuffers {
     double *out = nullptr;     // [kBatch][T]
     double *queue = nullptr;   // [kBatch][n_remote]
     BatchState *state = nullptr;
-    uint8_t *row_w = nullptr;  // [rows][kBatch], tile order
-    uint32_t *row_w_all = nullptr; // [kBatch][R] u32, caller order (drawn or injected)
+    uint8_t *row_w = nullptr;  // [rows][kBatch], tile order: one byte per slot
     uint32_t *overflow = nullptr;
     BatchState *h_state = nullptr; // pinned
     double *h_out = nullptr;       // pinned [kBatch][T]
@@ -219,7 +218,8 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 int launch_batch_pass(oem_store *s, const BatchBuffers &bb);
 int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p);
 int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot);
-int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w_all, const BatchBuffers &bb, uint32_t *d_overflow);
+int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w, const BatchBuffers &bb, uint32_t slot,
+                            uint32_t *d_overflow);
 
 int launch_aux_counts(oem_store *s, uint32_t *d_unique, uint32_t *d_total);
 int launch_assignment_probs(oem_store *s, const double *d_counts, double display_thresh, double *d_out);

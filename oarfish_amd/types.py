@@ -200,6 +200,13 @@ class DeviceStore:
         self._check(self._lib.oem_time_em_iters(self.handle, n_iters, C.byref(ms)))
         return float(ms.value)
 
+    def time_bootstrap_passes(self, n_passes: int):
+        """(ms per batched bootstrap pass, replicates per pass, algorithmic bytes per batched pass)."""
+        ms, slots, nbytes = C.c_float(0), C.c_uint32(0), C.c_uint64(0)
+        self._check(self._lib.oem_time_bootstrap_passes(self.handle, n_passes, C.byref(ms), C.byref(slots),
+                                                        C.byref(nbytes)))
+        return float(ms.value), int(slots.value), int(nbytes.value)
+
     def attach_comm(self, comm_handle, global_n_reads: int, global_row_offset: int):
         self._check(self._lib.oem_store_attach_comm(self.handle, comm_handle, global_n_reads,
                                                     global_row_offset))
