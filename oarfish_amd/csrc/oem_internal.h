@@ -114,7 +114,10 @@ struct DeviceTiled {
 // (oem_batch_kernels.hip).  Per-slot loop state, walked on the device:
 // RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
-constexpr int kBatch = 8;
+#ifndef OEM_KBATCH
+#define OEM_KBATCH 8
+#endif
+constexpr int kBatch = OEM_KBATCH;
 enum : uint32_t { kPhaseRunning = 0, kPhaseFinal = 1, kPhaseFinished = 2 };
 
 struct BatchState {

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""A few batched bootstrap passes on a C3-shaped store (profiling target)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oarfish_amd import synth, _lib
+from oarfish_amd.types import DeviceStore
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+ctx = _lib.testing() if os.environ.get("OEM_USE_TESTING_LIB") == "1" else None
+if ctx:
+    ctx.__enter__()
+st = synth.make_config(wl)
+with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+    ms, slots, nbytes = d.time_bootstrap_passes(n)
+    print(f"batched pass: {ms:.4f} ms for {slots} replicates = {ms / slots * 1e3:.1f} us per replicate-pass; "
+          f"{nbytes / ms / 1e6:.0f} GB/s algorithmic")
