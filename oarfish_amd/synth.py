@@ -167,13 +167,21 @@ def make_config(name: str, coverage: bool = False, seed_offset: int = 0, **over)
 
 
 def make_cells(n_cells: int, reads_per_cell: int, n_txps: int, kbar: float = 8.0,
-               seed: int = BASE_SEED + 5, expressed_frac: float = 0.1):
-    """C5: concatenated per-cell stores.  Each cell expresses a random subset of genes."""
+               seed: int = BASE_SEED + 5, expressed_frac: float = 0.1, first_cell: int = 0, threads: int = 1):
+    """C5: concatenated per-cell stores.  Cell c is a pure function of (seed, c), so ranks that each
+    generate a block of cells (``first_cell``) produce pieces of one experiment."""
+    def one(c):
+        return make_store(reads_per_cell, n_txps, kbar, seed=seed * 1000 + first_cell + c, threads=1)
+
+    if threads > 1 and n_cells > 1:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            stores = list(ex.map(one, range(n_cells)))
+    else:
+        stores = [one(c) for c in range(n_cells)]
     rps, tids, ps = [np.zeros(1, dtype=np.uint64)], [], []
     cell_off = np.zeros(n_cells + 1, dtype=np.uint64)
     base = 0
-    for c in range(n_cells):
-        st = make_store(reads_per_cell, n_txps, kbar, seed=seed * 1000 + c, threads=1)
+    for c, st in enumerate(stores):
         rps.append(st.row_ptr[1:] + np.uint64(base))
         tids.append(st.tid)
         ps.append(st.as_prob)

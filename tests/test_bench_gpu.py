@@ -1,0 +1,59 @@
+"""GPU tests of bench.py itself: the driver's contract line, and the whole multi-GPU code path
+(process group, native RCCL communicator, attach, barrier / all-reduce timing, replica-parallel
+bootstraps, dealt cells) forced onto a world of one rank -- what an 8-GPU node will execute."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def _check_contract(d, steps, warmup):
+    assert d["metric"] == "EM iterations/sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0
+    assert d["scaling"] == "strong" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    b = d["bootstraps"]
+    assert b["value"] > 0 and b["n"] == 3 and b["roofline"]["achieved"] > 0 and b["roofline"]["replicates_per_launch"] == 8
+    c = d["cells"]
+    assert c["value"] > 0 and c["n_cells"] == 4 and c["worst_mass_error"] < 1e-6 * c["reads_per_cell"]
+    for name in ("em", "em_par"):
+        assert d["em_to_convergence"][name]["n_passes"] >= 3
+
+
+@pytest.mark.timeout(900)
+def test_bench_contract_line_single_process():
+    cmd = [sys.executable, "bench.py", "--workload", "tiny", "--steps", "6", "--warmup", "2", "--bootstraps", "3",
+           "--cells", "4", "--cpu-seconds", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    _check_contract(d, 6, 2)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "forced" not in d["config"]["parallelism"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_forced_dist_path_under_torchrun():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29587", "bench.py", "--gpus", "1", "--workload", "tiny",
+           "--steps", "6", "--warmup", "2", "--bootstraps", "3", "--cells", "4", "--no-cpu-baseline", "--force-dist"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _last_json(p.stdout)
+    _check_contract(d, 6, 2)
+    assert "forced dist path" in d["config"]["parallelism"]
+    assert "replica-parallel" in d["bootstraps"]["mode"] and d["cpu_baseline"] is None
