@@ -114,6 +114,42 @@ int validate_csr(const uint64_t *row_ptr, const uint32_t *tid, uint64_t n_reads,
     return OEM_OK;
 }
 
+// A NaN in the coverage column (normalize_read_probs lets the 0/0 of a zero-span alignment through,
+// normalize_probability.rs:58) makes the read's denominator NaN in the reference, the test
+// `denom > 1e-30` fails and the read contributes nothing (em.rs:115).  The kernels are branch-free
+// (x * (c / denom), inv = 0 for a dropped read), where a NaN weight would survive as NaN * 0: such reads are
+// therefore given all-zero coverage at upload, which drops them the same way.  Returns the reads found;
+// `fixed` is filled (a copy of the column) only when there are any.
+uint64_t zero_nan_rows(const uint64_t *row_ptr, const double *cov, uint64_t n_reads, uint64_t nnz,
+                       std::vector<double> *fixed)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1 || nnz < (1u << 20)) nt = 1;
+    std::vector<std::vector<uint64_t>> bad(nt);
+    auto scan = [&](unsigned k) {
+        const uint64_t r0 = n_reads * k / nt, r1 = n_reads * (k + 1) / nt;
+        for (uint64_t r = r0; r < r1; ++r)
+            for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
+                if (cov[j] != cov[j]) { bad[k].push_back(r); break; }
+    };
+    if (nt == 1) {
+        scan(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; ++k) th.emplace_back(scan, k);
+        for (auto &t : th) t.join();
+    }
+    uint64_t n_bad = 0;
+    for (auto &v : bad) n_bad += v.size();
+    if (n_bad == 0) return 0;
+    fixed->assign(cov, cov + nnz);
+    for (auto &v : bad)
+        for (uint64_t r : v)
+            for (uint64_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) (*fixed)[j] = 0.0;
+    return n_bad;
+}
+
 struct RunArgs {
     const double *init = nullptr; // host, n_txps, or NULL
     const uint32_t *d_row_w = nullptr; // device multiplicities or NULL
@@ -634,12 +670,14 @@ extern "C" const char *oem_last_error(void) { return t_err; }
 
 extern "C" int oem_device_count(int *out_count)
 {
+    OEM_API_BEGIN
     if (!out_count) return fail(OEM_ERR_ARG, "oem_device_count: out_count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) n = 0;
     *out_count = n;
     return OEM_OK;
+    OEM_API_END("oem_device_count")
 }
 
 // ---------------------------------------------------------------------------
@@ -650,6 +688,7 @@ extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, co
                                 uint32_t n_txps, int device, const oem_store_opts *opts,
                                 oem_store **out)
 {
+    OEM_API_BEGIN
     if (!out) return fail(OEM_ERR_ARG, "oem_store_create: out is NULL");
     *out = nullptr;
     if (!row_ptr) return fail(OEM_ERR_ARG, "oem_store_create: row_ptr is NULL");
@@ -657,6 +696,8 @@ extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, co
     if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_store_create: n_txps is 0");
     StageTimer tm;
     OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps));
+    std::vector<double> cov_fixed;
+    if (cov_prob && zero_nan_rows(row_ptr, cov_prob, n_reads, nnz, &cov_fixed)) cov_prob = cov_fixed.data();
     tm.lap("validate_csr");
     OEM_TRY(ensure_device(device));
     oem_store *s = new (std::nothrow) oem_store();
@@ -668,21 +709,25 @@ extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, co
     }
     *out = s;
     return OEM_OK;
+    OEM_API_END("oem_store_create")
 }
 
 extern "C" void oem_store_destroy(oem_store *store) { free_store(store); }
 
 extern "C" int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uint32_t *n_txps)
 {
+    OEM_API_BEGIN
     if (!store) return fail(OEM_ERR_ARG, "oem_store_dims: store is NULL");
     if (n_reads) *n_reads = store->csr.n_reads;
     if (nnz) *nnz = store->csr.nnz;
     if (n_txps) *n_txps = store->csr.n_txps;
     return OEM_OK;
+    OEM_API_END("oem_store_dims")
 }
 
 extern "C" int oem_store_set_option(oem_store *store, uint32_t option, uint64_t value)
 {
+    OEM_API_BEGIN
     if (!store) return fail(OEM_ERR_ARG, "oem_store_set_option: store is NULL");
     std::lock_guard<std::mutex> lk(store->mu);
     switch (option) {
@@ -693,10 +738,12 @@ extern "C" int oem_store_set_option(oem_store *store, uint32_t option, uint64_t 
         return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_store_set_option: unknown option %u", option);
     }
+    OEM_API_END("oem_store_set_option")
 }
 
 extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass)
 {
+    OEM_API_BEGIN
     if (!store) return fail(OEM_ERR_ARG, "oem_store_bytes: store is NULL");
     const DeviceCsr &m = store->csr;
     if (hbm_bytes) *hbm_bytes = store->hbm_bytes;
@@ -705,6 +752,7 @@ extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint
         *algorithmic_bytes_per_pass = m.nnz * (4 + (m.w_is_f64 ? 8 : 4)) +
                                       (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) + 2ull * m.n_txps * 8;
     return OEM_OK;
+    OEM_API_END("oem_store_bytes")
 }
 
 // ---------------------------------------------------------------------------
@@ -712,6 +760,7 @@ extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint
 // ---------------------------------------------------------------------------
 extern "C" int oem_m_step(oem_store *s, const double *theta, const uint32_t *row_w, double *out_counts)
 {
+    OEM_API_BEGIN
     if (!s || !theta || !out_counts) return fail(OEM_ERR_ARG, "oem_m_step: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -732,12 +781,14 @@ extern "C" int oem_m_step(oem_store *s, const double *theta, const uint32_t *row
     if (comm_exchanges(s->comm))
         OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
     return copy_counts_out(s, out_counts);
+    OEM_API_END("oem_m_step")
 }
 
 extern "C" int oem_em_run(oem_store *s, const double *init_abundances, uint32_t max_iter,
                           double conv_thresh, uint32_t min_iter_gate, double *out_counts,
                           oem_run_info *info)
 {
+    OEM_API_BEGIN
     if (!s || !out_counts) return fail(OEM_ERR_ARG, "oem_em_run: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -751,6 +802,7 @@ extern "C" int oem_em_run(oem_store *s, const double *init_abundances, uint32_t 
     a.min_iter_gate = min_iter_gate;
     OEM_TRY(run_em_device(s, a, info));
     return copy_counts_out(s, out_counts);
+    OEM_API_END("oem_em_run")
 }
 
 // ---------------------------------------------------------------------------
@@ -758,6 +810,7 @@ extern "C" int oem_em_run(oem_store *s, const double *init_abundances, uint32_t 
 // ---------------------------------------------------------------------------
 extern "C" int oem_aux_counts(oem_store *s, uint32_t *out_unique, uint32_t *out_total)
 {
+    OEM_API_BEGIN
     if (!s || !out_unique || !out_total) return fail(OEM_ERR_ARG, "oem_aux_counts: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -773,10 +826,12 @@ extern "C" int oem_aux_counts(oem_store *s, uint32_t *out_unique, uint32_t *out_
         rc = fail(OEM_ERR_HIP, "oem_aux_counts: read-back failed");
     hipFree(d);
     return rc;
+    OEM_API_END("oem_aux_counts")
 }
 
 extern "C" int oem_assignment_probs(oem_store *s, const double *counts, double display_thresh, double *out_prob)
 {
+    OEM_API_BEGIN
     if (!s || !counts || (s->csr.nnz && !out_prob)) return fail(OEM_ERR_ARG, "oem_assignment_probs: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -794,6 +849,7 @@ extern "C" int oem_assignment_probs(oem_store *s, const double *counts, double d
         rc = fail(OEM_ERR_HIP, "oem_assignment_probs: read-back failed");
     hipFree(d_out);
     return rc;
+    OEM_API_END("oem_assignment_probs")
 }
 
 // ---------------------------------------------------------------------------
@@ -801,6 +857,7 @@ extern "C" int oem_assignment_probs(oem_store *s, const double *counts, double d
 // ---------------------------------------------------------------------------
 extern "C" int oem_bootstrap_weights(oem_store *s, uint64_t seed, uint32_t replica, uint32_t *out_row_w)
 {
+    OEM_API_BEGIN
     if (!s || !out_row_w) return fail(OEM_ERR_ARG, "oem_bootstrap_weights: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -810,12 +867,14 @@ extern "C" int oem_bootstrap_weights(oem_store *s, uint64_t seed, uint32_t repli
     OEM_HIP(hipMemcpyAsync(out_row_w, s->d_row_w, sizeof(uint32_t) * s->csr.n_reads, hipMemcpyDeviceToHost, s->stream));
     OEM_HIP(hipStreamSynchronize(s->stream));
     return OEM_OK;
+    OEM_API_END("oem_bootstrap_weights")
 }
 
 extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all,
                              const double *init_abundances, uint32_t max_iter, double conv_thresh,
                              double *out, oem_run_info *infos)
 {
+    OEM_API_BEGIN
     if (!s || (n_boot && !out)) return fail(OEM_ERR_ARG, "oem_bootstrap: NULL argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -853,6 +912,7 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
         OEM_TRY(copy_counts_out(s, out + (uint64_t)b * T));
     }
     return OEM_OK;
+    OEM_API_END("oem_bootstrap")
 }
 
 // ---------------------------------------------------------------------------
@@ -1039,6 +1099,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
                                 uint32_t max_iter, double conv_thresh, double *out,
                                 oem_run_info *infos)
 {
+    OEM_API_BEGIN
     if (!cell_row_off || !row_ptr || (n_cells && !out)) return fail(OEM_ERR_ARG, "oem_em_run_cells: NULL argument");
     if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_em_run_cells: n_txps is 0");
     if (cell_row_off[0] != 0 || cell_row_off[n_cells] != n_reads)
@@ -1077,6 +1138,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         c0 = c1;
     }
     return OEM_OK;
+    OEM_API_END("oem_em_run_cells")
 }
 
 // ---------------------------------------------------------------------------
@@ -1085,6 +1147,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
 extern "C" int oem_store_attach_comm(oem_store *s, oem_comm *comm, uint64_t global_n_reads,
                                      uint64_t global_row_offset)
 {
+    OEM_API_BEGIN
     if (!s) return fail(OEM_ERR_ARG, "oem_store_attach_comm: store is NULL");
     if (global_row_offset + s->csr.n_reads > global_n_reads)
         return fail(OEM_ERR_ARG, "oem_store_attach_comm: shard [%llu,+%llu) exceeds %llu reads",
@@ -1095,6 +1158,7 @@ extern "C" int oem_store_attach_comm(oem_store *s, oem_comm *comm, uint64_t glob
     s->global_n_reads = global_n_reads;
     s->global_row_offset = global_row_offset;
     return OEM_OK;
+    OEM_API_END("oem_store_attach_comm")
 }
 
 // ---------------------------------------------------------------------------
@@ -1102,6 +1166,7 @@ extern "C" int oem_store_attach_comm(oem_store *s, oem_comm *comm, uint64_t glob
 // ---------------------------------------------------------------------------
 extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg_ms)
 {
+    OEM_API_BEGIN
     if (!s || !out_avg_ms || n_launches == 0) return fail(OEM_ERR_ARG, "oem_time_m_step: bad argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -1125,10 +1190,12 @@ extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg
     hipEventDestroy(e1);
     *out_avg_ms = ms / (float)n_launches;
     return OEM_OK;
+    OEM_API_END("oem_time_m_step")
 }
 
 extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
 {
+    OEM_API_BEGIN
     if (!s || !out_ms) return fail(OEM_ERR_ARG, "oem_time_em_iters: bad argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -1155,11 +1222,13 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     hipEventDestroy(e1);
     *out_ms = ms;
     return OEM_OK;
+    OEM_API_END("oem_time_em_iters")
 }
 
 extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
                                          uint64_t *out_algorithmic_bytes)
 {
+    OEM_API_BEGIN
     if (!s || !out_avg_ms || n_passes == 0) return fail(OEM_ERR_ARG, "oem_time_bootstrap_passes: bad argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
@@ -1207,4 +1276,5 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
                                  (uint64_t)kBatch * (m.n_reads * 4 + 2ull * m.n_txps * 8);
     }
     return OEM_OK;
+    OEM_API_END("oem_time_bootstrap_passes")
 }

@@ -30,6 +30,7 @@ using namespace oem;
 extern "C" int oem_builder_create(const oem_filters *filters, const uint64_t *txp_len, uint32_t n_txps,
                                   oem_builder **out)
 {
+    OEM_API_BEGIN
     if (!filters || !txp_len || !out || n_txps == 0) return fail(OEM_ERR_ARG, "oem_builder_create: bad argument");
     oem_builder *b = new (std::nothrow) oem_builder();
     if (!b) return fail(OEM_ERR_OOM, "oem_builder_create: host allocation failed");
@@ -37,15 +38,20 @@ extern "C" int oem_builder_create(const oem_filters *filters, const uint64_t *tx
     b->txp_len.assign(txp_len, txp_len + n_txps);
     *out = b;
     return OEM_OK;
+    OEM_API_END("oem_builder_create")
 }
 
 extern "C" void oem_builder_destroy(oem_builder *b) { delete b; }
 
 extern "C" int oem_builder_add_group(oem_builder *b, const oem_aln_record *ag, uint32_t n, uint32_t *out_kept)
 {
+    OEM_API_BEGIN
     if (!b || (n && !ag)) return fail(OEM_ERR_ARG, "oem_builder_add_group: NULL argument");
     if (out_kept) *out_kept = 0;
     if (n == 0) return OEM_OK;                                    // add_group: `if !ag.is_empty()` (:677)
+    for (uint32_t i = 0; i < n; ++i)   // every argument error is reported before the discard table is touched
+        if (!(ag[i].flags & OEM_REC_UNMAPPED) && ag[i].ref_id >= b->txp_len.size())
+            return fail(OEM_ERR_ARG, "oem_builder_add_group: ref_id %u is not below n_txps", ag[i].ref_id);
     const oem_filters &F = b->f;
     oem_discard_table &dt = b->dt;
 
@@ -63,8 +69,6 @@ extern "C" int oem_builder_add_group(oem_builder *b, const oem_aln_record *ag, u
     for (uint32_t i = 0; i < n; ++i) {
         const oem_aln_record &x = ag[i];
         if (x.flags & OEM_REC_UNMAPPED) continue;                 // :987
-        if (x.ref_id >= b->txp_len.size())
-            return fail(OEM_ERR_ARG, "oem_builder_add_group: ref_id %u is not below n_txps", x.ref_id);
         const uint32_t aln_span = x.aln_span;                     // :991
         const int32_t score = (x.flags & OEM_REC_HAS_SCORE) ? (int32_t)x.score : INT32_MIN; // :994
         const bool is_rc = x.flags & OEM_REC_REVERSE;             // :997
@@ -114,26 +118,32 @@ extern "C" int oem_builder_add_group(oem_builder *b, const oem_aln_record *ag, u
     if (n_kept) b->row_ptr.push_back(b->tid.size());              // add_filtered_group (:724-735)
     if (out_kept) *out_kept = n_kept;
     return OEM_OK;
+    OEM_API_END("oem_builder_add_group")
 }
 
 extern "C" int oem_builder_dims(const oem_builder *b, uint64_t *n_reads, uint64_t *nnz)
 {
+    OEM_API_BEGIN
     if (!b) return fail(OEM_ERR_ARG, "oem_builder_dims: builder is NULL");
     if (n_reads) *n_reads = b->row_ptr.size() - 1;
     if (nnz) *nnz = b->tid.size();
     return OEM_OK;
+    OEM_API_END("oem_builder_dims")
 }
 
 extern "C" int oem_builder_discard_table(const oem_builder *b, oem_discard_table *out)
 {
+    OEM_API_BEGIN
     if (!b || !out) return fail(OEM_ERR_ARG, "oem_builder_discard_table: NULL argument");
     *out = b->dt;
     return OEM_OK;
+    OEM_API_END("oem_builder_discard_table")
 }
 
 extern "C" int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint32_t *tid, float *as_prob,
                                   uint32_t *start, uint32_t *end, uint8_t *strand)
 {
+    OEM_API_BEGIN
     if (!b) return fail(OEM_ERR_ARG, "oem_builder_export: builder is NULL");
     const size_t nnz = b->tid.size();
     if (row_ptr) std::memcpy(row_ptr, b->row_ptr.data(), sizeof(uint64_t) * b->row_ptr.size());
@@ -143,6 +153,7 @@ extern "C" int oem_builder_export(const oem_builder *b, uint64_t *row_ptr, uint3
     if (end && nnz) std::memcpy(end, b->end.data(), sizeof(uint32_t) * nnz);
     if (strand && nnz) std::memcpy(strand, b->strand.data(), nnz);
     return OEM_OK;
+    OEM_API_END("oem_builder_export")
 }
 
 // ---------------------------------------------------------------------------
@@ -296,10 +307,13 @@ static int coverage_probs_impl(const oem_builder *b, uint32_t bin_width_u, CovMo
                     cov_prob += w * tx.prob[i];
                 }
             }
-            const double expected = cov_prob / total_weight;           // :58
-            if (std::isnan(cov_prob) || std::isinf(cov_prob) || std::isnan(expected)) // :49-57 (+ the 0/0 of an empty bin range)
+            // :49-57: the reference panics on a non-finite cov_prob only.  A 0/0 expected value (zero-span
+            // alignment, empty bin range) is not an error there: the NaN flows into the column, the row sum
+            // fails `> 0` (:62), and the EM drops the read because its denominator is not > 1e-30 (em.rs:115).
+            if (std::isnan(cov_prob) || std::isinf(cov_prob))
                 return fail(OEM_ERR_STATE, "normalize_read_probs: invalid coverage probability for alignment %llu",
                             (unsigned long long)j);
+            const double expected = cov_prob / total_weight;           // :58
             out[j] = expected;
             nprob_sum += expected;
         }
@@ -311,27 +325,35 @@ static int coverage_probs_impl(const oem_builder *b, uint32_t bin_width_u, CovMo
 
 extern "C" int oem_builder_coverage_probs(const oem_builder *b, uint32_t bin_width, double growth_rate, double *out)
 {
+    OEM_API_BEGIN
     return coverage_probs_impl(b, bin_width, CovModel::Logistic, growth_rate, out);
+    OEM_API_END("oem_builder_coverage_probs")
 }
 
 extern "C" int oem_builder_coverage_probs_binomial(const oem_builder *b, uint32_t bin_width, double *out)
 {
+    OEM_API_BEGIN
     return coverage_probs_impl(b, bin_width, CovModel::Binomial, 0.0, out);
+    OEM_API_END("oem_builder_coverage_probs_binomial")
 }
 
 extern "C" int oem_builder_coverage_probs_device(const oem_builder *b, uint32_t bin_width, int model, double growth_rate,
                                                  int device, double *out)
 {
+    OEM_API_BEGIN
     if (!b) return fail(OEM_ERR_ARG, "oem_builder_coverage_probs_device: builder is NULL");
     return oem_coverage_probs_device(b->row_ptr.data(), b->tid.data(), b->start.data(), b->end.data(), b->txp_len.data(),
                                      b->row_ptr.size() - 1, b->tid.size(), (uint32_t)b->txp_len.size(), bin_width, model,
                                      growth_rate, device, out);
+    OEM_API_END("oem_builder_coverage_probs_device")
 }
 
 extern "C" int oem_builder_store_create(const oem_builder *b, const double *cov_prob, int device,
                                         const oem_store_opts *opts, oem_store **out)
 {
+    OEM_API_BEGIN
     if (!b || !out) return fail(OEM_ERR_ARG, "oem_builder_store_create: NULL argument");
     return oem_store_create(b->row_ptr.data(), b->tid.data(), b->as_prob.data(), cov_prob,
                             b->row_ptr.size() - 1, b->tid.size(), (uint32_t)b->txp_len.size(), device, opts, out);
+    OEM_API_END("oem_builder_store_create")
 }

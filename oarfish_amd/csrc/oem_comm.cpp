@@ -183,6 +183,7 @@ static_assert(sizeof(ncclUniqueId) == OEM_UNIQUE_ID_BYTES, "unique id size");
 
 extern "C" int oem_comm_unique_id(void *out_id)
 {
+    OEM_API_BEGIN
     if (!out_id) return fail(OEM_ERR_ARG, "oem_comm_unique_id: out_id is NULL");
     OEM_TRY(load_rccl());
     ncclUniqueId id;
@@ -190,11 +191,13 @@ extern "C" int oem_comm_unique_id(void *out_id)
     if (r != 0) return fail(OEM_ERR_RCCL, "ncclGetUniqueId: %s", nccl_err(r));
     std::memcpy(out_id, &id, sizeof(id));
     return OEM_OK;
+    OEM_API_END("oem_comm_unique_id")
 }
 
 extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int device,
                                oem_comm **out)
 {
+    OEM_API_BEGIN
     if (!out) return fail(OEM_ERR_ARG, "oem_comm_create: out is NULL");
     *out = nullptr;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
@@ -222,12 +225,14 @@ extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int
     }
     *out = reinterpret_cast<oem_comm *>(c);
     return OEM_OK;
+    OEM_API_END("oem_comm_create")
 }
 
 #ifdef OEM_TESTING
 // Test hook (not in the public header): n_ranks communicators of one process-local group.
 extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **out /* [n_ranks] */)
 {
+    OEM_API_BEGIN
     if (n_ranks < 1 || !out) return fail(OEM_ERR_ARG, "oem_debug_local_comm_create: bad argument");
     auto g = std::make_shared<LocalGroup>();
     g->n = n_ranks;
@@ -243,6 +248,7 @@ extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **o
         out[r] = reinterpret_cast<oem_comm *>(c);
     }
     return OEM_OK;
+    OEM_API_END("oem_debug_local_comm_create")
 }
 #endif // OEM_TESTING
 

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kCT) void k_cov_reads(const uint32_t *__restrict__ 
             }
         }
         const double expected = cov_prob / total_weight;                           // :58
-        if (isnan(cov_prob) || isinf(cov_prob) || isnan(expected)) atomicOr(err, kErrNonFinite); // :49-57
+        if (isnan(cov_prob) || isinf(cov_prob)) atomicOr(err, kErrNonFinite); // :49-57 (a 0/0 expected value is not an error there)
         out[j] = expected;
         nprob_sum += expected;
     }
@@ -230,6 +230,7 @@ extern "C" int oem_coverage_probs_device(const uint64_t *row_ptr, const uint32_t
                                          uint64_t nnz, uint32_t n_txps, uint32_t bin_width, int model,
                                          double growth_rate, int device, double *out_cov_prob)
 {
+    OEM_API_BEGIN
     if (!row_ptr || !txp_len || (nnz && (!tid || !aln_start || !aln_end || !out_cov_prob)))
         return fail(OEM_ERR_ARG, "oem_coverage_probs_device: NULL argument");
     if (bin_width == 0)
@@ -296,4 +297,5 @@ extern "C" int oem_coverage_probs_device(const uint64_t *row_ptr, const uint32_t
     if (h_err & kErrNonFinite) return fail(OEM_ERR_STATE, "coverage model: non-finite probability");
     OEM_HIP(hipMemcpy(out_cov_prob, d_out, sizeof(double) * nnz, hipMemcpyDeviceToHost));
     return OEM_OK;
+    OEM_API_END("oem_coverage_probs_device")
 }

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,14 @@ int fail(int code, const char *fmt, ...);
                                "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
                                __FILE__, __LINE__);                                        \
     } while (0)
+
+// The ABI promises never to throw across the boundary: every `extern "C" int` body sits between these.
+#define OEM_API_BEGIN try {
+#define OEM_API_END(name)                                                                          \
+    }                                                                                              \
+    catch (const std::bad_alloc &) { return ::oem::fail(OEM_ERR_OOM, "%s: host allocation failed", name); } \
+    catch (const std::exception &e) { return ::oem::fail(OEM_ERR_STATE, "%s: %s", name, e.what()); } \
+    catch (...) { return ::oem::fail(OEM_ERR_STATE, "%s: unknown C++ exception", name); }
 
 #define OEM_TRY(expr)                 \
     do {                              \

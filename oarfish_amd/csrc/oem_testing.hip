@@ -17,6 +17,7 @@ using namespace oem;
 // r_row, r_slot, q_dst, bucket_base; out[14] (if asked for) = 1 when the device built it; returns OEM_ERR_STATE when the store has no tiled layout.
 extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out)
 {
+    OEM_API_BEGIN
     if (!s || !out || n_out < 14) return fail(OEM_ERR_ARG, "oem_debug_layout_hash: bad argument");
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_HIP(hipSetDevice(s->device));
@@ -52,6 +53,7 @@ extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out
     OEM_TRY(hash_dev(t.bucket_base, 4 * ((size_t)t.n_buckets + 1), &out[13]));
     if (n_out > 14) out[14] = t.built_on_device ? 1 : 0;
     return OEM_OK;
+    OEM_API_END("oem_debug_layout_hash")
 }
 
 
@@ -91,6 +93,7 @@ __global__ void k_stress_record(const EmState *state, double *out, uint32_t laun
 extern "C" int oem_test_reldiff_stress(uint32_t n_txps, uint32_t n_launches, uint32_t seed, int device,
                                        double *out_last_rel /* n_launches */)
 {
+    OEM_API_BEGIN
     if (!n_txps || !n_launches || !out_last_rel) return fail(OEM_ERR_ARG, "oem_test_reldiff_stress: bad argument");
     OEM_HIP(hipSetDevice(device));
     oem_store s; // only the stream is used by the launcher
@@ -125,4 +128,5 @@ extern "C" int oem_test_reldiff_stress(uint32_t n_txps, uint32_t n_launches, uin
     hipStreamDestroy(s.stream);
     s.stream = nullptr;
     return rc;
+    OEM_API_END("oem_test_reldiff_stress")
 }

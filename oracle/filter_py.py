@@ -224,7 +224,11 @@ def coverage_probs(st: Store, txp_len, bin_width: int, growth_rate: float, model
                     w = (min(bl * float(i) + bl, tlen) - sa) / bl if i == sb else 1.0
                     tw += w
                     cp += w * prob[t][i]
-            out[j] = cp / tw
+            if math.isnan(cp) or math.isinf(cp):                  # :49-57: the only panic of this function
+                raise ValueError("Error: Invalid result. normalize_read_probs function.")
+            # f64 division as Rust does it: 0/0 is NaN, not an exception (:58); the NaN makes the row sum
+            # fail `> 0` (:62) and the EM later drops the read (em.rs:115)
+            out[j] = float(np.float64(cp) / np.float64(tw)) if tw != 0.0 else (float("nan") if cp == 0.0 else math.copysign(float("inf"), cp))
             s += out[j]
         d = s if s > 0 else 1.0
         for j in range(st.row_ptr[r], st.row_ptr[r + 1]):

@@ -386,3 +386,62 @@ def test_device_coverage_model_matches_the_oracle(model, seed, bin_width, growth
     live = sums > 0
     np.testing.assert_allclose(sums[live], 1.0, rtol=1e-12)      # normalised per read
     assert live.mean() > 0.9
+
+
+def _store_with_a_zero_span_alignment():
+    """A read whose second alignment has start == end: total_weight = 0 and cov_prob = 0 in
+    normalize_read_probs, so its expected value is 0/0 = NaN (normalize_probability.rs:58) -- which the
+    reference does NOT treat as an error (only a non-finite cov_prob panics, :49-57)."""
+    rng = np.random.default_rng(61)
+    T = 12
+    txp_len = rng.integers(900, 3000, size=T)
+    F = fp.Filters()
+    F.min_aligned_len, F.min_aligned_fraction = 0, 0.0
+    h = _builder(F, txp_len)
+    ref = fp.Store()
+    for r in range(300):
+        t0 = int(rng.integers(0, T))
+        g = [fp.Rec(t0, 10, 700, 690, 1500, 700)]
+        if r % 50 == 7:
+            g.append(fp.Rec(int((t0 + 1) % T), 333, 333, 0, 1490, None))          # zero span, same bin
+        else:
+            g.append(fp.Rec(int((t0 + 1) % T), 20, 650, 630, 1480, None))
+        assert _add(h, g) == fp.add_group(ref, F, txp_len, g) == 2
+    return h, ref, txp_len, T
+
+
+def test_zero_span_alignment_gives_nan_coverage_as_in_the_reference():
+    h, ref, txp_len, T = _store_with_a_zero_span_alignment()
+    rp, tid, p, s, e, sd, dt = _export(h)
+    cov = np.zeros(len(tid))
+    _lib.check(_lib.lib().oem_builder_coverage_probs(h, 100, 2.0, cov.ctypes.data))     # OEM_OK, not OEM_ERR_STATE
+    _lib.lib().oem_builder_destroy(h)
+    want = np.asarray(fp.coverage_probs(ref, txp_len, 100, 2.0))
+    assert np.isnan(want).sum() == 6 and np.array_equal(np.isnan(cov), np.isnan(want))   # that alignment only; the row stays un-normalised (:62)
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(cov[ok], want[ok], rtol=1e-15)
+
+
+@pytest.mark.gpu
+def test_nan_coverage_reads_are_dropped_by_the_em_as_in_the_reference():
+    """em.rs:115: a NaN denominator fails `denom > 1e-30`, the read contributes nothing.  Device coverage
+    model -> NaN column -> store -> EM, against the oracle on the same column."""
+    from oracle import c_oracle
+    h, ref, txp_len, T = _store_with_a_zero_span_alignment()
+    rp, tid, p, s, e, sd, dt = _export(h)
+    cov = np.zeros(len(tid))
+    _lib.check(_lib.lib().oem_builder_coverage_probs_device(h, 100, 0, 2.0, 0, cov.ctypes.data))
+    want_cov = np.asarray(fp.coverage_probs(ref, txp_len, 100, 2.0))
+    assert np.array_equal(np.isnan(cov), np.isnan(want_cov)) and np.isnan(cov).sum() == 6
+    hs = C.c_void_p()
+    _lib.check(_lib.lib().oem_builder_store_create(h, cov.ctypes.data, 0, None, C.byref(hs)))
+    out = np.zeros(T)
+    ri = _lib.RunInfoC()
+    _lib.check(_lib.lib().oem_em_run(hs, None, 300, 1e-3, 50, out.ctypes.data, C.byref(ri)))
+    _lib.lib().oem_store_destroy(hs)
+    _lib.lib().oem_builder_destroy(h)
+    want, wi = c_oracle.do_em(c_oracle.Store(rp, tid, p, cov, T), max_iter=300, conv_thresh=1e-3)
+    assert np.all(np.isfinite(out)) and np.all(np.isfinite(want))
+    assert abs(out.sum() - (300 - 6)) < 1e-9 * 300 and abs(want.sum() - (300 - 6)) < 1e-9 * 300   # six reads dropped
+    assert abs(ri.niter - wi.niter) <= 1
+    np.testing.assert_allclose(out, want, rtol=1e-8, atol=1e-9)
