@@ -6,8 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oarfish_amd
 from oarfish_amd import synth
 n_cells, rpc, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-cell_off, row_ptr, tid, p = synth.make_cells(n_cells, rpc, T, seed=3)
+cell_off, row_ptr, tid, p = synth.make_cells(n_cells, rpc, T, seed=3, threads=min(32, os.cpu_count() or 4))
 from oarfish_amd import _lib
+if os.environ.get("OEM_SERIAL_CELLS"):   # the cell-by-cell path is a knob of the test-only library
+    _lib.testing().__enter__()
 _lib.lib()  # load the library (and the process's HIP runtime) outside the timed region
 t = time.perf_counter()
 out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=1000, convergence_thresh=1e-3)
