@@ -7,9 +7,8 @@ _lib.lib()
 for R, T in ((100_000, 200_000), (200_000, 200_000), (250_000, 300_000), (400_000, 200_000), (120_000, 60_000), (2_000_000, 4_000_000)):
     st = synth.make_store(R, T, 8.0, threads=32)
     out = []
-    for cap in ("512", "2048"):
-        os.environ["OEM_WIN_CAP"] = cap
-        d = DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T)
+    for cap in (512, 2048):
+        d = DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T, window_cap=cap)   # oem_store_opts.window_cap
         d.time_em_iters(10)
         out.append(d.time_em_iters(200) / 200)
         d.close()
