@@ -775,6 +775,22 @@ def test_full_size_c3_properties():
         assert np.all(full >= u - 1e-6) and np.all(full <= t + 1e-6)
         w = d.bootstrap_weights(3, 0)
         assert int(w.sum()) == st.n_reads and abs(w.var() - 1.0) < 0.01
+        # The batched bootstrap at full size (k_em_tile_e: 8 slots per pass, two epochs): a short fixed
+        # number of iterations of a drawn resample and of the identity resample against the oracle, ...
+        W = np.stack([w, np.ones(st.n_reads, dtype=np.uint32), d.bootstrap_weights(3, 2)])
+        bout, binfo = d.bootstrap(3, row_w_all=W, max_iter=8, conv_thresh=0.0)
+        for b in (0, 1):
+            wantb, _ = c_oracle.do_em(o, row_w=W[b], max_iter=8, conv_thresh=0.0)   # the serial oracle, ~0.2 s per pass
+            assert binfo[b].niter == 8 and binfo[b].n_passes == 9
+            assert_counts_close(bout[b], wantb, st.n_reads, st.n_txps, 1e-8, f"c3 batched bootstrap, replicate {b}")
+        # ... and to convergence: the identity resample through the batch kernels must walk the point
+        # estimate's trajectory (gate 50) and stop where it stops
+        point, pinfo = d.em_run(None, 1000, 1e-3, 50)
+        ident, iinfo = d.bootstrap(2, row_w_all=W[1:3], max_iter=1000, conv_thresh=1e-3)
+        assert abs(iinfo[0].niter - pinfo.niter) <= 1
+        assert_counts_close(ident[0], point, st.n_reads, st.n_txps, RTOL if iinfo[0].niter != pinfo.niter else 1e-8,
+                            "identity resample through the batch path")
+        assert abs(ident[1].sum() - st.n_reads) < 1e-7 * st.n_reads           # a resample keeps the read count
 
 
 @pytest.mark.parametrize("name", ["c2"])
