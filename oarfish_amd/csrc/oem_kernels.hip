@@ -93,8 +93,15 @@ __global__ __launch_bounds__(kRB) void k_reldiff_swap_clear(double *__restrict__
         double m = smax[0];
         for (int i = 1; i < kRB / 64; ++i) m = fmax(m, smax[i]);
         // non-negative doubles order like their bit patterns.  Both this and the ticket below are
-        // device-scope atomics resolved at the memory side; draining the max (vmcnt) before taking
-        // the ticket orders them without a cache write-back/invalidate (~3.5 us each on MI355X).
+        // device-scope read-modify-write atomics, performed at the one point of coherence of their
+        // line (memory side), and on gfx9 a no-return atomic is counted by vmcnt until it has been
+        // performed there: draining vmcnt before taking the ticket means the maximum is in place
+        // before the ticket can be observed, so the workgroup that draws the last ticket reads (with
+        // an agent-scope atomic load) a maximum that contains every workgroup's.  A release fence
+        // here would add an L2 write-back (buffer_wbl2) that publishes nothing this decision needs
+        // (~3.5 us per workgroup tail, measured in round 1).  The election is hammered in isolation
+        // by oem_test_reldiff_stress (test-only library): > 10^5 launches over 1..64 workgroups,
+        // planted maxima, the decision workgroup's view compared bit for bit.
         if (m > 0.0) atomicMax(&state->rel_bits, (unsigned long long)__double_as_longlong(m));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t ticket = atomicAdd(&state->blocks_arrived, 1u);
