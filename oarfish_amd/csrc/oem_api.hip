@@ -932,10 +932,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     StageTimer tm;
     const uint64_t total_txps = (uint64_t)n_cells * n_txps;
     if (max_iter < 1 || n_cells < 2 || total_txps >= (1ull << 32) || n_reads >= (1ull << 32)) return OEM_OK;
-    for (uint64_t j = 0; j < nnz; ++j)
-        if (tid[j] >= n_txps)
-            return fail(OEM_ERR_ARG, "tid[%llu]=%u is not below n_txps=%u", (unsigned long long)j, tid[j], n_txps);
-    tm.lap("cells: validate");
+    tm.lap("cells: group set-up");   // (the arrays were range-checked once by oem_em_run_cells)
     OEM_TRY(ensure_device(device));
     oem_store *s = new (std::nothrow) oem_store();
     if (!s) return fail(OEM_ERR_OOM, "oem_em_run_cells: host allocation failed");
@@ -1108,9 +1105,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         if (cell_row_off[c + 1] < cell_row_off[c])
             return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off not non-decreasing at cell %u", c);
     if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_em_run_cells: tid/as_prob is NULL");
-    for (uint64_t i = 0; i < n_reads; ++i)
-        if (row_ptr[i + 1] < row_ptr[i]) return fail(OEM_ERR_ARG, "row_ptr is not non-decreasing at read %llu", (unsigned long long)i);
-    if (row_ptr[0] != 0 || row_ptr[n_reads] != nnz) return fail(OEM_ERR_ARG, "oem_em_run_cells: row_ptr must span [0, nnz]");
+    OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps)); // all cells at once, on several host threads
 
     // Cells are independent problems, so a large experiment is cut into groups of consecutive cells
     // that bound the batched store (transcript space < 2^32, <= 2^30 alignments, and the layout
