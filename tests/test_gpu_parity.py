@@ -958,3 +958,54 @@ def test_stopping_rule_kernel_under_stress():
         assert len(bad) == 0, f"T={T}: {len(bad)} of {n} launches saw a stale maximum, first at launch {bad[:5]}: {out[bad[:5]]}"
         total += n
     assert total > 100_000
+
+
+@pytest.mark.timeout(300)
+def test_sharded_bootstrap_routes_every_replicate_the_same_way_on_all_ranks():
+    """Row shards decide per replicate between the 8-slot batch and the one-per-pass path (a multiplicity
+    >= 256 does not fit the batch's byte).  The decision selects which collectives run, so it must be taken
+    together: here the oversized multiplicity sits in ONE shard only, and a second replicate makes one
+    shard's whole block of reads vanish (multiplicity 0).  Two real shards as threads over the test-only
+    library's process-local communicator; results against the un-sharded store and the oracle."""
+    import ctypes as C
+    import threading
+    from oarfish_amd import _lib, dist as odist
+    st = synth.make_store(50_000, 3_000, seed=733)
+    rng = np.random.default_rng(2)
+    n_boot, world = 10, 2
+    W = np.stack([np.bincount(rng.integers(0, st.n_reads, st.n_reads), minlength=st.n_reads)
+                  for _ in range(n_boot)]).astype(np.uint32)
+    W[3, :] = 0
+    W[3, 7] = 700                      # rank 0's shard overflows the byte, rank 1's does not
+    W[6, st.n_reads // 2:] = 0         # (roughly) rank 1's reads all drop out of replicate 6
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    with _lib.testing():
+        handles = (C.c_void_p * world)()
+        _lib.check(_lib.lib().oem_debug_local_comm_create(world, 0, C.addressof(handles)))
+        res, errs = [None] * world, []
+
+        def rank_main(rank):
+            try:
+                sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, rank, world)
+                with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps) as d:
+                    d.attach_comm(C.c_void_p(handles[rank]), st.n_reads, sh.row_begin)
+                    res[rank] = d.bootstrap(n_boot, row_w_all=np.ascontiguousarray(W[:, sh.row_begin:sh.row_end]),
+                                            max_iter=150, conv_thresh=1e-3)
+            except Exception as e:  # pragma: no cover
+                errs.append((rank, repr(e)))
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=200)
+        assert not errs and all(r is not None for r in res), errs
+        for r in range(world):
+            _lib.lib().oem_comm_destroy(C.c_void_p(handles[r]))
+    assert np.array_equal(res[0][0], res[1][0])                     # every rank holds the same reduced counts
+    for b in range(n_boot):
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=150, conv_thresh=1e-3)
+        gi = res[0][1][b]
+        assert gi.niter == res[1][1][b].niter and abs(gi.niter - wi.niter) <= 1, (b, gi, wi)
+        assert_counts_close(res[0][0][b], want, st.n_reads, st.n_txps, RTOL if gi.niter != wi.niter else 1e-8,
+                            f"sharded replicate {b}")
