@@ -1009,3 +1009,88 @@ def test_sharded_bootstrap_routes_every_replicate_the_same_way_on_all_ranks():
         assert gi.niter == res[1][1][b].niter and abs(gi.niter - wi.niter) <= 1, (b, gi, wi)
         assert_counts_close(res[0][0][b], want, st.n_reads, st.n_txps, RTOL if gi.niter != wi.niter else 1e-8,
                             f"sharded replicate {b}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Size-independent properties of the E/M pass and the EM through the C ABI (the oracle is pinned by
+# constructed vectors only, so these hold the device path to the algebra of em.rs:87-133 directly).
+# ---------------------------------------------------------------------------------------------------
+def _random_store(seed, R=30_000, T=2_500, maxk=12):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, maxk + 1, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, 40, size=nnz)) % T).astype(np.uint32)
+    far = rng.random(nnz) < 0.15
+    tid[far] = rng.integers(0, T, size=int(far.sum()))
+    p = np.exp(-rng.integers(0, 30, size=nnz) / 5.0).astype(np.float32)
+    return rp, tid, p, lens, rng
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_properties_of_one_pass(seed):
+    rp, tid, p, lens, rng = _random_store(seed)
+    R, T = len(lens), 2_500
+    theta = rng.lognormal(0, 2, size=T)
+    theta[rng.random(T) < 0.2] = 0.0
+    with DeviceStore(rp, tid, p, None, T) as d:
+        base = d.m_step(theta)
+        # (1) an abundance of zero stays zero; the mass that is left is the reads with a positive denominator
+        assert np.all(base[theta == 0.0] == 0.0)
+        live = np.add.reduceat((theta[tid] * p.astype(np.float64)), rp[:-1].astype(np.int64)) > 1e-30
+        assert abs(base.sum() - live.sum()) < 1e-9 * R
+        # (2) linearity in the read multiplicities, and multiplicity 2 == the read stored twice
+        w = rng.integers(0, 4, size=R).astype(np.uint32)
+        assert_counts_close(d.m_step(theta, w) + d.m_step(theta, (3 - w).astype(np.uint32)), 3.0 * base, R, T, 1e-10, "linearity")
+    # (3) the order of the reads does not matter (em.rs:97 sums over reads)
+    perm = rng.permutation(R)
+    starts = rp[:-1].astype(np.int64)[perm]
+    idx = np.concatenate([np.arange(s, s + l) for s, l in zip(starts, lens[perm])])
+    rp2 = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.uint64)
+    with DeviceStore(rp2, tid[idx], p[idx], None, T) as d2:
+        assert_counts_close(d2.m_step(theta), base, R, T, 1e-10, "row permutation")
+    # (4) scaling a read's weights by a power of two changes nothing: x / denom is invariant (exactly, in f64)
+    scale = np.repeat(2.0 ** rng.integers(-3, 1, size=R), lens).astype(np.float32)
+    with DeviceStore(rp, tid, (p * scale).astype(np.float32), None, T) as d3:
+        assert_counts_close(d3.m_step(theta), base, R, T, 1e-12, "row scaling")
+    # (5) the store twice over == twice the counts
+    rp4 = np.concatenate([rp, rp[1:] + rp[-1]]).astype(np.uint64)
+    with DeviceStore(rp4, np.concatenate([tid, tid]), np.concatenate([p, p]), None, T) as d4:
+        assert_counts_close(d4.m_step(theta), 2.0 * base, R, T, 1e-10, "duplicated store")
+
+
+def test_em_fixed_point_is_idempotent_and_scale_free():
+    """Running the EM from its own converged output moves nothing beyond the threshold, and the result does
+    not depend on the scale of the initial abundances' common factor beyond fp (the E-step normalises)."""
+    rp, tid, p, lens, rng = _random_store(11, R=40_000, T=1_500)
+    R, T = len(lens), 1_500
+    with DeviceStore(rp, tid, p, None, T) as d:
+        a, ai = d.em_run(None, 2000, 1e-6, 50)
+        b, bi = d.em_run(a, 2000, 1e-6, 50)
+        assert ai.converged and bi.converged and bi.niter <= 52        # already at the fixed point: the gate only
+        assert_counts_close(b, a, R, T, 1e-2, "restart from the fixed point")  # 52 more passes at rel-diff < 1e-6 each
+        c, ci = d.em_run(a * 8.0, 2000, 1e-6, 50)                      # theta scaled by 8: same posteriors
+        assert_counts_close(c, b, R, T, 1e-9, "scaled restart")
+        assert abs(a.sum() - R) < 1e-7 * R
+
+
+def test_hot_transcripts_do_not_break_the_layout():
+    """Every read on the same three transcripts (64 lanes adding into one LDS entry) and a store with a
+    single transcript: correctness at the worst case of the window atomics."""
+    rng = np.random.default_rng(5)
+    R = 200_000
+    lens = rng.integers(1, 4, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tid = np.concatenate([np.arange(l) for l in lens]).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 10, size=int(rp[-1])) / 5.0).astype(np.float32)
+    o = c_oracle.Store(rp, tid, p, None, 3)
+    want, wi = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3)
+    with DeviceStore(rp, tid, p, None, 3) as d:
+        got, gi = d.em_run(None, 200, 1e-3, 50)
+        boot, binfo = d.bootstrap(9, seed=4, max_iter=100)
+        assert np.all(np.abs(boot.sum(axis=1) - R) < 1e-6 * R)
+    assert abs(gi.niter - wi.niter) <= 1
+    assert_counts_close(got, want, R, 3, RTOL if gi.niter != wi.niter else 1e-9, "three hot transcripts")
+    with DeviceStore(np.arange(1001, dtype=np.uint64), np.zeros(1000, np.uint32), np.ones(1000, np.float32), None, 1) as d:
+        cnt, _ = d.em_run(None, 60, 1e-3, 50)
+        assert cnt[0] == 1000.0
