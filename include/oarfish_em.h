@@ -104,8 +104,9 @@ void oem_store_destroy(oem_store *store);
 /* Tuning switches of a store (not part of the reference's semantics; results are
  * unchanged up to floating-point summation order). */
 typedef enum {
-    OEM_OPT_BATCH_BOOTSTRAP = 1, /* value 1 (default): oem_bootstrap runs 8 replicates per pass over the
-                                    matrix when it can (f32 weights, multiplicities < 256); 0: one per pass */
+    OEM_OPT_BATCH_BOOTSTRAP = 1, /* value 1 (default): oem_bootstrap runs its replicates in batches that share
+                                    each pass over the matrix (4 per pass, two such chains side by side on their
+                                    own streams) when it can (f32 weights, multiplicities < 256); 0: one per pass */
     OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2 /* value b0 (default 0): replicate k of the next oem_bootstrap calls
                                     draws the device resample of global replica b0 + k.  Lets N processes
                                     that each hold the whole store split one set of replicates with no

@@ -5,6 +5,8 @@
 //   bulk.rs:155-159   em::em / em::em_par      -> oem_em_run
 //   bulk.rs:178-194   em::bootstrap            -> oem_bootstrap
 //   single_cell.rs:139-160  per-cell em::em    -> oem_em_run_cells
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -252,11 +254,14 @@ int ensure_row_w(oem_store *s)
     return OEM_OK;
 }
 
-int ensure_batch(oem_store *s)
+int ensure_batch(oem_store *s, int chain)
 {
-    BatchBuffers &b = s->batch;
+    BatchBuffers &b = s->batch[chain];
     if (b.theta) return OEM_OK;
     const size_t T = s->csr.n_txps;
+    if (chain == 0) b.stream = s->stream;
+    else OEM_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    OEM_TRY(dev_alloc(&b.d_row_w, s->csr.n_reads, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.theta, T * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.cnt, 2 * T * kBatch, &s->hbm_bytes));
     b.cnt2 = b.cnt + T * kBatch;
@@ -264,7 +269,7 @@ int ensure_batch(oem_store *s)
     OEM_TRY(dev_alloc(&b.queue, (size_t)s->tiled.n_remote * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 16, &s->hbm_bytes));
-    OEM_HIP(hipMemsetAsync(b.row_w, 0, (size_t)s->tiled.n_rows * kBatch + 16, s->stream));
+    OEM_HIP(hipMemsetAsync(b.row_w, 0, (size_t)s->tiled.n_rows * kBatch + 16, b.stream));
     OEM_TRY(dev_alloc(&b.overflow, 1, &s->hbm_bytes));
     OEM_HIP(hipHostMalloc((void **)&b.h_state, sizeof(BatchState) * kBatch, hipHostMallocDefault));
     OEM_HIP(hipHostMalloc((void **)&b.h_out, sizeof(double) * T * kBatch, hipHostMallocDefault));
@@ -293,65 +298,75 @@ int agree_any(oem_store *s, bool *flag)
     return OEM_OK;
 }
 
-// Rolling batch: kBatch slots share every pass over the matrix; a slot whose replicate has finished
-// is handed the next replicate at once, so the slots stay busy until the replicates run out (with
-// fixed groups the pass count of a group is its largest, and every group pays its own set-up).
-// Replicates whose multiplicities do not fit a byte are returned in `fallback` (one-per-pass path).
-int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all, const double *init,
-                          uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos,
-                          std::vector<uint32_t> *fallback)
+// What the chains of one oem_bootstrap call share: the replicates are handed out from one counter.
+struct BootJob {
+    uint32_t n_boot = 0;
+    uint64_t seed = 0;
+    const uint32_t *row_w_all = nullptr; // host, n_boot x R, or NULL
+    const double *d_init = nullptr;      // device, or NULL => uniform
+    uint32_t max_iter = 0;
+    double conv_thresh = 0.0;
+    double *out = nullptr;
+    oem_run_info *infos = nullptr;
+    std::atomic<uint32_t> next{0};
+    std::mutex mu;                       // guards `fallback`
+    std::vector<uint32_t> fallback;      // replicates with a multiplicity >= 256: one-per-pass path
+};
+
+// One chain of the rolling batch: kBatch slots share every pass over the matrix; a slot whose replicate
+// has finished is handed the next replicate of the job at once, so the slots stay busy until the
+// replicates run out (with fixed groups the pass count of a group is its largest, and every group pays
+// its own set-up).  Every call of it runs on its own stream with its own buffers, so kChains of them run
+// side by side (threads of oem_bootstrap): the streaming fold / rel-diff kernels of one chain overlap the
+// tile kernel of the other (two chains: +10 % bootstraps/s at C3; three or four add nothing).
+int run_bootstrap_chain(oem_store *s, int chain, BootJob *job)
 {
-    OEM_TRY(ensure_batch(s));
-    BatchBuffers &bb = s->batch;
+    BatchBuffers &bb = s->batch[chain];
+    hipStream_t st = bb.stream;
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
-    const double *d_init = nullptr;
-    if (init) {
-        OEM_HIP(hipMemcpyAsync(s->theta, init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
-        d_init = s->theta;
-    }
     const double avg = (double)s->global_n_reads / (double)T; // em.rs:154: the store's read count also for a replicate
-    EmParams p{T, max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, conv_thresh};
+    EmParams p{T, job->max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, job->conv_thresh};
     const bool sharded = comm_exchanges(s->comm);
     int slot_rep[kBatch];
-    uint32_t next = 0;
-    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
+    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, st));
     for (int k = 0; k < kBatch; ++k) {
         slot_rep[k] = -1;
         std::memset(&bb.h_state[k], 0, sizeof(BatchState));
         bb.h_state[k].phase = kPhaseFinished;
     }
-    OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
+    OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, st));
 
     // hands slot k the next replicate that fits (or leaves it idle when none is left)
     auto load = [&](int k) -> int {
-        while (next < n_boot) {
-            const uint32_t rep = next++;
-            if (row_w_all) {
-                OEM_HIP(hipMemcpyAsync(s->d_row_w, row_w_all + (size_t)rep * R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, s->stream));
+        for (;;) {
+            const uint32_t rep = job->next.fetch_add(1);
+            if (rep >= job->n_boot) return OEM_OK;
+            if (job->row_w_all) {
+                OEM_HIP(hipMemcpyAsync(bb.d_row_w, job->row_w_all + (size_t)rep * R, sizeof(uint32_t) * R, hipMemcpyHostToDevice, st));
             } else {
-                OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset, s->global_n_reads, seed,
-                                                 s->bootstrap_first_replica + rep)); // em.rs:274-276
+                OEM_TRY(launch_bootstrap_weights(s, bb.d_row_w, R, s->global_row_offset, s->global_n_reads, job->seed,
+                                                 s->bootstrap_first_replica + rep, st)); // em.rs:274-276
             }
-            OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
-            OEM_TRY(launch_batch_pack_row_w(s, s->d_row_w, bb, (uint32_t)k, bb.overflow));
+            OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), st));
+            OEM_TRY(launch_batch_pack_row_w(s, bb.d_row_w, bb, (uint32_t)k, bb.overflow));
             uint32_t h_overflow = 0;
-            OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-            OEM_HIP(hipStreamSynchronize(s->stream));
+            OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            OEM_HIP(hipStreamSynchronize(st));
             bool over = h_overflow != 0;
-            OEM_TRY(agree_any(s, &over)); // row shards: every rank must route the replicate the same way
+            OEM_TRY(agree_any(s, &over)); // row shards (one chain): every rank must route the replicate the same way
             if (over) { // a multiplicity >= 256: this replicate goes to the one-per-pass path
-                fallback->push_back(rep);
+                std::lock_guard<std::mutex> lk(job->mu);
+                job->fallback.push_back(rep);
                 continue; // (the slot's byte column is rewritten by the next replicate it is handed)
             }
-            OEM_TRY(launch_batch_reset_slot(s, bb, d_init, avg, (uint32_t)k));
+            OEM_TRY(launch_batch_reset_slot(s, bb, job->d_init, avg, (uint32_t)k));
             std::memset(&bb.h_state[k], 0, sizeof(BatchState));
             bb.h_state[k].phase = kPhaseRunning;
-            OEM_HIP(hipMemcpyAsync(&bb.state[k], &bb.h_state[k], sizeof(BatchState), hipMemcpyHostToDevice, s->stream));
+            OEM_HIP(hipMemcpyAsync(&bb.state[k], &bb.h_state[k], sizeof(BatchState), hipMemcpyHostToDevice, st));
             slot_rep[k] = (int)rep;
             return OEM_OK;
         }
-        return OEM_OK;
     };
     for (int k = 0; k < kBatch; ++k) OEM_TRY(load(k));
 
@@ -364,29 +379,76 @@ int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const ui
         first = false;
         for (uint32_t i = 0; i < chunk; ++i) {
             OEM_TRY(launch_batch_pass(s, bb));
-            if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, 2 * (size_t)T * kBatch, s->stream));
+            if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, 2 * (size_t)T * kBatch, st));
             OEM_TRY(launch_batch_reldiff(s, bb, p));
         }
-        OEM_HIP(hipMemcpyAsync(bb.h_state, bb.state, sizeof(BatchState) * kBatch, hipMemcpyDeviceToHost, s->stream));
-        OEM_HIP(hipStreamSynchronize(s->stream));
+        OEM_HIP(hipMemcpyAsync(bb.h_state, bb.state, sizeof(BatchState) * kBatch, hipMemcpyDeviceToHost, st));
+        OEM_HIP(hipStreamSynchronize(st));
         for (int k = 0; k < kBatch; ++k) {
             if (slot_rep[k] < 0 || bb.h_state[k].phase != kPhaseFinished) continue;
             const uint32_t rep = (uint32_t)slot_rep[k];
             OEM_HIP(hipMemcpyAsync(bb.h_out + (size_t)k * T, bb.out + (size_t)k * T, sizeof(double) * T,
-                                   hipMemcpyDeviceToHost, s->stream));
-            OEM_HIP(hipStreamSynchronize(s->stream));
-            std::memcpy(out + (size_t)rep * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
-            if (infos) {
-                infos[rep].niter = bb.h_state[k].niter;
-                infos[rep].n_passes = bb.h_state[k].n_passes;
-                infos[rep].converged = bb.h_state[k].converged;
-                infos[rep].reserved = 0;
-                infos[rep].rel_diff = bb.h_state[k].last_rel;
+                                   hipMemcpyDeviceToHost, st));
+            OEM_HIP(hipStreamSynchronize(st));
+            std::memcpy(job->out + (size_t)rep * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
+            if (job->infos) {
+                job->infos[rep].niter = bb.h_state[k].niter;
+                job->infos[rep].n_passes = bb.h_state[k].n_passes;
+                job->infos[rep].converged = bb.h_state[k].converged;
+                job->infos[rep].reserved = 0;
+                job->infos[rep].rel_diff = bb.h_state[k].last_rel;
             }
             slot_rep[k] = -1;
             OEM_TRY(load(k));
         }
     }
+    return OEM_OK;
+}
+
+// The batched bootstrap: kChains chains (one host thread each) over the one resident matrix.  A row-sharded
+// store runs a single chain: its per-pass all-reduces must be issued in the same order on every rank.
+int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const uint32_t *row_w_all, const double *init,
+                          uint32_t max_iter, double conv_thresh, double *out, oem_run_info *infos,
+                          std::vector<uint32_t> *fallback)
+{
+    const uint32_t T = s->csr.n_txps;
+    BootJob job;
+    job.n_boot = n_boot; job.seed = seed; job.row_w_all = row_w_all; job.max_iter = max_iter;
+    job.conv_thresh = conv_thresh; job.out = out; job.infos = infos;
+    int n_chains = comm_exchanges(s->comm) ? 1 : kChains;
+    if (n_boot <= (uint32_t)kBatch) n_chains = 1; // one chain holds them all
+    n_chains = (int)knob("OEM_BOOT_CHAINS", n_chains) < n_chains ? (int)knob("OEM_BOOT_CHAINS", n_chains) : n_chains;
+    if (n_chains < 1) n_chains = 1;
+    for (int c = 0; c < n_chains; ++c) OEM_TRY(ensure_batch(s, c));
+    if (init) {
+        OEM_HIP(hipMemcpyAsync(s->theta, init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+        job.d_init = s->theta;
+    }
+    OEM_HIP(hipStreamSynchronize(s->stream)); // the init vector and the buffers' set-up are in place for every chain
+    int rcs[kChains];
+    std::string errs[kChains];
+    for (int c = 0; c < kChains; ++c) rcs[c] = OEM_OK;
+    auto body = [&](int c) {
+        if (hipSetDevice(s->device) != hipSuccess) {
+            rcs[c] = OEM_ERR_HIP;
+            errs[c] = "hipSetDevice failed in a bootstrap chain";
+            return;
+        }
+        try {
+            rcs[c] = run_bootstrap_chain(s, c, &job);
+        } catch (const std::exception &e) {
+            rcs[c] = fail(OEM_ERR_OOM, "bootstrap chain: %s", e.what());
+        }
+        if (rcs[c] != OEM_OK) errs[c] = t_err; // t_err is thread-local
+    };
+    std::vector<std::thread> th;
+    for (int c = 1; c < n_chains; ++c) th.emplace_back(body, c);
+    body(0);
+    for (auto &t : th) t.join();
+    for (int c = 0; c < n_chains; ++c)
+        if (rcs[c] != OEM_OK) return fail(rcs[c], "%s", errs[c].c_str());
+    *fallback = job.fallback;
+    std::sort(fallback->begin(), fallback->end());
     return OEM_OK;
 }
 
@@ -406,8 +468,10 @@ void free_store(oem_store *s)
         hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.queue);
         hipFree(t.row_w_perm);
     }
-    {
-        oem::BatchBuffers &b = s->batch;
+    for (int c = 0; c < oem::kChains; ++c) {
+        oem::BatchBuffers &b = s->batch[c];
+        if (c > 0 && b.stream) { hipStreamSynchronize(b.stream); hipStreamDestroy(b.stream); }
+        hipFree(b.d_row_w);
         hipFree(b.theta); hipFree(b.cnt); hipFree(b.out); hipFree(b.queue); hipFree(b.state);
         hipFree(b.row_w); hipFree(b.overflow);
         if (b.h_state) hipHostFree(b.h_state);
@@ -1228,17 +1292,16 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
     std::lock_guard<std::mutex> lk(s->mu);
     OEM_TRY(ensure_device(s->device));
     if (!can_batch(s)) return fail(OEM_ERR_STATE, "oem_time_bootstrap_passes: this store runs its bootstraps one per pass");
-    OEM_TRY(ensure_row_w(s));
-    OEM_TRY(ensure_batch(s));
-    BatchBuffers &bb = s->batch;
+    OEM_TRY(ensure_batch(s, 0));
+    BatchBuffers &bb = s->batch[0];
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
     const double avg = (double)s->global_n_reads / (double)T;
     OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
     for (int k = 0; k < kBatch; ++k) { // every slot RUNNING on its own device-drawn resample
-        OEM_TRY(launch_bootstrap_weights(s, s->d_row_w, R, s->global_row_offset, s->global_n_reads, 0x7e57ull, (uint32_t)k));
+        OEM_TRY(launch_bootstrap_weights(s, bb.d_row_w, R, s->global_row_offset, s->global_n_reads, 0x7e57ull, (uint32_t)k));
         OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));
-        OEM_TRY(launch_batch_pack_row_w(s, s->d_row_w, bb, (uint32_t)k, bb.overflow));
+        OEM_TRY(launch_batch_pack_row_w(s, bb.d_row_w, bb, (uint32_t)k, bb.overflow));
         OEM_TRY(launch_batch_reset_slot(s, bb, nullptr, avg, (uint32_t)k));
         std::memset(&bb.h_state[k], 0, sizeof(BatchState));
         bb.h_state[k].phase = kPhaseRunning;

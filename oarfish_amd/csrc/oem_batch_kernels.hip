@@ -2,7 +2,9 @@
 //
 // em::bootstrap (em.rs:292-314) runs num_boot independent resampled EMs, each a serial
 // do_em over random_sampling_iter (em.rs:273-290); every replicate streams the whole store
-// again.  Here kBatch = 8 replicates ("slots") share one pass over the tiled matrix.
+// again.  Here kBatch replicates ("slots") share one pass over the tiled matrix, and kChains such
+// batches run side by side on their own HIP streams (oem_api.hip): one chain's streaming fold /
+// rel-diff kernels run under another's tile kernel.
 //
 // What amortises and what does not.  The matrix streams (weights, window codes, remote
 // records: ~0.65 GB at 10 M reads) and the L2 requests of the remote theta gathers are paid
@@ -497,11 +499,11 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * 6 + t.n_remote * 14;
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
     if (nt)
-        hipLaunchKernelGGL((k_em_tile_e<true>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, s->stream, t.tiles, t.codes,
+        hipLaunchKernelGGL((k_em_tile_e<true>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,
                            (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
                            t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
     else
-        hipLaunchKernelGGL((k_em_tile_e<false>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, s->stream, t.tiles, t.codes,
+        hipLaunchKernelGGL((k_em_tile_e<false>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,
                            (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
                            t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
     OEM_HIP(hipGetLastError());
@@ -511,7 +513,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         const uint32_t max_useful = (uint32_t)((per_bucket + 32767) / 32768);
         if (n_groups > max_useful) n_groups = max_useful;
         if (n_groups < 1) n_groups = 1;
-        hipLaunchKernelGGL(k_remote_fold_b, dim3(kB * t.n_buckets * n_groups), dim3(kFoldThreadsB), 0, s->stream,
+        hipLaunchKernelGGL(k_remote_fold_b, dim3(kB * t.n_buckets * n_groups), dim3(kFoldThreadsB), 0, bb.stream,
                            t.bucket_base, bb.queue, t.n_remote, t.q_dst, bb.cnt2, bb.state, n_groups,
                            t.n_buckets, s->csr.n_txps);
         OEM_HIP(hipGetLastError());
@@ -523,7 +525,7 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 {
     // the sweep moves kB times the bytes of k_reldiff_swap_clear: 256 workgroups (97 -> ~30 us at 200 k transcripts)
     const int grid = grid_for(p.n_txps, kRelB, 256);
-    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
+    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, bb.stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
                        bb.state, p);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
@@ -532,7 +534,7 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot)
 {
     const int grid = grid_for(s->csr.n_txps, 256, 256);
-    hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, s->stream, bb.theta, bb.cnt, bb.cnt2, d_init, avg,
+    hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, bb.stream, bb.theta, bb.cnt, bb.cnt2, d_init, avg,
                        s->csr.n_txps, slot);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
@@ -543,7 +545,7 @@ int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w, const BatchBu
 {
     const uint64_t n = s->tiled.n_rows;
     if (n == 0) return OEM_OK;
-    hipLaunchKernelGGL(k_pack_row_w_b, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s->stream, d_row_w,
+    hipLaunchKernelGGL(k_pack_row_w_b, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, bb.stream, d_row_w,
                        s->tiled.perm, n, bb.row_w, slot, d_overflow);
     OEM_HIP(hipGetLastError());
     return OEM_OK;

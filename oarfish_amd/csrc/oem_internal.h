@@ -125,9 +125,10 @@ struct DeviceTiled {
 // RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
 #ifndef OEM_KBATCH
-#define OEM_KBATCH 8
+#define OEM_KBATCH 4
 #endif
-constexpr int kBatch = OEM_KBATCH;
+constexpr int kBatch = OEM_KBATCH; // slots of one chain: the replicates that share a pass over the matrix
+constexpr int kChains = 2;         // chains running side by side, each with its own stream and buffers
 enum : uint32_t { kPhaseRunning = 0, kPhaseFinal = 1, kPhaseFinished = 2 };
 
 struct BatchState {
@@ -144,6 +145,8 @@ struct BatchState {
 static_assert(sizeof(BatchState) == 48, "BatchState layout");
 
 struct BatchBuffers {
+    hipStream_t stream = nullptr; // the chain's own stream (chain 0: the store's)
+    uint32_t *d_row_w = nullptr;  // n_reads u32: the replicate being handed to a slot, caller order
     double *theta = nullptr;   // [T][kBatch]
     double *cnt = nullptr;     // [T][kBatch]  (tile-kernel flushes)   } contiguous: one all-reduce
     double *cnt2 = nullptr;    // [kBatch][T]  (fold-kernel flushes)   }
@@ -184,7 +187,7 @@ struct oem_store {
     oem::EmState *h_state = nullptr;     // pinned
     uint32_t *d_row_w = nullptr;         // bootstrap multiplicities, n_reads u32
     double *h_pinned = nullptr;          // pinned staging, n_txps f64
-    oem::BatchBuffers batch;             // lazily allocated by the batched bootstrap
+    oem::BatchBuffers batch[oem::kChains]; // lazily allocated by the batched bootstrap
     oem::MultiBuffers multi;             // per-cell batches
     uint32_t bootstrap_first_replica = 0; // OEM_OPT_BOOTSTRAP_FIRST_REPLICA
     bool batch_bootstrap = true;         // OEM_OPT_BATCH_BOOTSTRAP (2 replicates per pass when applicable)
@@ -238,7 +241,7 @@ int launch_aux_counts(oem_store *s, uint32_t *d_unique, uint32_t *d_total);
 int launch_assignment_probs(oem_store *s, const double *d_counts, double display_thresh, double *d_out);
 int launch_fill(oem_store *s, double *p, double v, uint64_t n);
 int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,
-                             uint64_t n_global, uint64_t seed, uint32_t replica);
+                             uint64_t n_global, uint64_t seed, uint32_t replica, hipStream_t stream = nullptr);
 
 // RCCL (oem_comm.cpp) ---------------------------------------------------------
 int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st);

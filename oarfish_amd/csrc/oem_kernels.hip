@@ -329,12 +329,13 @@ int launch_fill(oem_store *s, double *p, double v, uint64_t n)
 }
 
 int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, uint64_t local_off,
-                             uint64_t n_global, uint64_t seed, uint32_t replica)
+                             uint64_t n_global, uint64_t seed, uint32_t replica, hipStream_t stream)
 {
-    OEM_HIP(hipMemsetAsync(row_w, 0, sizeof(uint32_t) * n_local, s->stream));
+    if (!stream) stream = s->stream;
+    OEM_HIP(hipMemsetAsync(row_w, 0, sizeof(uint32_t) * n_local, stream));
     if (n_global == 0) return OEM_OK;
     const int grid = grid_for((n_global + 1) / 2, kBlock, 256 * 16);
-    hipLaunchKernelGGL(k_bootstrap_weights, dim3(grid), dim3(kBlock), 0, s->stream, row_w, n_local,
+    hipLaunchKernelGGL(k_bootstrap_weights, dim3(grid), dim3(kBlock), 0, stream, row_w, n_local,
                        local_off, n_global, seed, replica);
     OEM_HIP(hipGetLastError());
     return OEM_OK;

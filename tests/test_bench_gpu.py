@@ -26,7 +26,7 @@ def _check_contract(d, steps, warmup):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     b = d["bootstraps"]
-    assert b["value"] > 0 and b["n"] == 3 and b["roofline"]["achieved"] > 0 and b["roofline"]["replicates_per_launch"] == 8
+    assert b["value"] > 0 and b["n"] == 3 and b["roofline"]["achieved"] > 0 and b["roofline"]["replicates_per_launch"] == 4 and b["chains"] == 2
     c = d["cells"]
     assert c["value"] > 0 and c["n_cells"] == 4 and c["worst_mass_error"] < 1e-6 * c["reads_per_cell"]
     for name in ("em", "em_par"):

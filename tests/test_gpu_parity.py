@@ -122,13 +122,14 @@ def test_bootstrap_inject_golden():
 
 
 def test_batched_bootstrap_matches_oracle_per_replicate():
-    """Replicates share passes over the matrix in a rolling batch of 8 slots (two epochs of four inside
-    the tile kernel; a finished slot is handed the next replicate, the tail runs with idle slots); every
-    replicate must still stop at its own iteration and match its own serial EM."""
+    """Replicates share passes over the matrix in rolling batches of 4 slots, two such chains side by side
+    on their own streams drawing replicates from one counter (a finished slot is handed the next replicate,
+    the tail runs with idle slots); every replicate must still stop at its own iteration and match its own
+    serial EM."""
     st = synth.make_store(40_000, 2_500, seed=81)
     o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
     rng = np.random.default_rng(8)
-    n_boot = 21  # 8 + 8 + 5: the slots are refilled twice, the last refill leaves three idle
+    n_boot = 21  # 2 chains x 4 slots, refilled twice; the tail leaves slots idle
     W = np.stack([np.bincount(rng.integers(0, st.n_reads, st.n_reads), minlength=st.n_reads)
                   for _ in range(n_boot)]).astype(np.uint32)
     W[5] = 1      # the un-resampled store: must equal the point estimate
