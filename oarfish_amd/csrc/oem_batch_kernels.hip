@@ -383,34 +383,33 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
         final_ |= (ph == kPhaseFinal) ? (1u << b) : 0u;
     }
     if (!(running | final_)) return;
-    double rel[kB];
-#pragma unroll
-    for (int b = 0; b < kB; ++b) rel[b] = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps; i += gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int b = 0; b < kB; ++b) {
-            if (!(((running | final_) >> b) & 1u)) continue;
-            const size_t ia = (size_t)i * kB + b, ib = (size_t)b * p.n_txps + i;
-            const double cc = cnt[ia] + cnt2[ib];
-            cnt[ia] = 0.0;
-            cnt2[ib] = 0.0;
-            if ((final_ >> b) & 1u) {
-                out[ib] = cc;                               // em.rs:254
-            } else {
-                const double pc = theta[ia];
-                if (pc > OEM_MIN_READ_THRESH) rel[b] = fmax(rel[b], (cc - pc) / pc); // em.rs:195-199
-                theta[ia] = cc;                             // em.rs:204 (zeroing of small values: k_em_tile_e reads them as 0)
-            }
+    // One (transcript, slot) element per thread per step, consecutive threads on consecutive elements of
+    // the [T][kB] arrays (fully coalesced; cnt2[b][.] is read in runs of 64 / kB transcripts).  The stride
+    // is a multiple of kB, so a thread stays on ONE slot, b = thread index mod kB, and the maxima of the kB
+    // slots are the kB residue classes of the lanes.
+    static_assert((kRelB % kB) == 0 && (64 % kB) == 0, "slot of a lane = lane mod kB");
+    const uint32_t b = threadIdx.x % kB;
+    const bool is_final = (final_ >> b) & 1u, is_live = ((running | final_) >> b) & 1u;
+    double rel = 0.0;
+    const size_t n_elem = (size_t)p.n_txps * kB;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_elem; j += (size_t)gridDim.x * blockDim.x) {
+        if (!is_live) continue;
+        const size_t i = j / kB, ib = (size_t)b * p.n_txps + i;
+        const double cc = cnt[j] + cnt2[ib];
+        cnt[j] = 0.0;
+        cnt2[ib] = 0.0;
+        if (is_final) {
+            out[ib] = cc;                               // em.rs:254
+        } else {
+            const double pc = theta[j];
+            if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
+            theta[j] = cc;                              // em.rs:204 (zeroing of small values: k_em_tile_e reads them as 0)
         }
     }
     __shared__ double smax[kRelB / 64][kB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int b = 0; b < kB; ++b) {
-        double r = rel[b];
-        for (int off = 32; off > 0; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
-        if (lane == 0) smax[wv][b] = r;
-    }
+    for (int off = 32; off >= kB; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64)); // within the lanes of one slot
+    if (lane < kB) smax[wv][lane] = rel;
     __syncthreads();
     __shared__ bool is_last;
     if (threadIdx.x == 0) {
