@@ -1095,3 +1095,61 @@ def test_hot_transcripts_do_not_break_the_layout():
     with DeviceStore(np.arange(1001, dtype=np.uint64), np.zeros(1000, np.uint32), np.ones(1000, np.float32), None, 1) as d:
         cnt, _ = d.em_run(None, 60, 1e-3, 50)
         assert cnt[0] == 1000.0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_batched_bootstrap_fuzz_random_shapes_match_oracle(seed):
+    """The batch kernels (k_em_tile_e / k_remote_fold_b / k_reldiff_b, two chains) over randomly shaped stores:
+    reads with up to 120 alignments (the register-resident eight per read overflow into the reload loops),
+    tiles with more remote alignments than the 3 x 512 kept in registers (the queue-parking path), empty reads,
+    1 .. 200 k transcripts, multiplicities up to 255 and all-zero resamples -- every replicate against the
+    oracle's serial EM with the same multiplicities."""
+    rng = np.random.default_rng(4200 + seed)
+    R = int(rng.choice([1, 40, 3_000, 30_000, 80_000]))
+    T = int(rng.choice([1, 6, 300, 4_000, 200_000]))
+    maxk = int(rng.choice([1, 6, 20, 120]))
+    lens = rng.integers(0, maxk + 1, size=R)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nnz = int(rp[-1])
+    spread = int(rng.choice([1, 10, 400, max(T, 1)]))
+    tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
+    n_boot = 11
+    W = rng.poisson(1.0, size=(n_boot, R)).astype(np.uint32)
+    W[2] = 0                                            # a resample that drew nothing (degenerate, but legal input)
+    if R > 3:
+        W[4, :3] = 255                                  # the largest multiplicity the batch takes
+        W[7, 1] = 256                                   # one more: this replicate goes to the one-per-pass path
+    o = c_oracle.Store(rp, tid, p, None, T)
+    with DeviceStore(rp, tid, p, None, T) as d:
+        out, infos = d.bootstrap(n_boot, row_w_all=W, max_iter=120, conv_thresh=1e-3)
+    what = f"seed {seed}: R={R} T={T} maxk={maxk} spread={spread}"
+    for b in range(n_boot):
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=120, conv_thresh=1e-3)
+        assert abs(infos[b].niter - wi.niter) <= 1, (what, b, infos[b], wi)
+        assert_counts_close(out[b], want, max(R, 1), T, RTOL if infos[b].niter != wi.niter else 1e-8, f"{what} replicate {b}")
+
+
+def test_batched_bootstrap_with_mostly_remote_alignments():
+    """40 alignments per read scattered over 100 k transcripts: ~40 k remote alignments per tile, far beyond
+    the 1536 a workgroup of k_em_tile_e keeps in registers -- the bulk of them takes the path that parks
+    theta * w in the queue between the two remote phases, for every slot of the batch."""
+    rng = np.random.default_rng(77)
+    R, T, k = 20_000, 100_000, 40
+    rp = (np.arange(R + 1) * k).astype(np.uint64)
+    tid = rng.integers(0, T, size=R * k).astype(np.uint32)
+    tid = np.sort(tid.reshape(R, k), axis=1)
+    tid += np.arange(k, dtype=np.uint32)[None, :] * 0          # (duplicates inside a read are legal input)
+    tid = tid.reshape(-1)
+    p = np.exp(-rng.integers(0, 25, size=R * k) / 5.0).astype(np.float32)
+    W = rng.poisson(1.0, size=(6, R)).astype(np.uint32)
+    o = c_oracle.Store(rp, tid, p, None, T)
+    with DeviceStore(rp, tid, p, None, T) as d:
+        out, infos = d.bootstrap(6, row_w_all=W, max_iter=80, conv_thresh=1e-3)
+        point, pinfo = d.em_run(None, 80, 1e-3, 50)
+    want, wi = c_oracle.do_em(o, max_iter=80, conv_thresh=1e-3)
+    assert_counts_close(point, want, R, T, RTOL if pinfo.niter != wi.niter else 1e-8, "point estimate")
+    for b in range(6):
+        want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=80, conv_thresh=1e-3)
+        assert abs(infos[b].niter - wi.niter) <= 1
+        assert_counts_close(out[b], want, R, T, RTOL if infos[b].niter != wi.niter else 1e-8, f"replicate {b}")
