@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _last_json(text):
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     assert lines, text[-2000:]
@@ -48,7 +55,7 @@ def test_bench_contract_line_single_process():
 @pytest.mark.timeout(900)
 def test_bench_forced_dist_path_under_torchrun():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-           "--master-addr", "127.0.0.1", "--master-port", "29587", "bench.py", "--gpus", "1", "--workload", "tiny",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--workload", "tiny",
            "--steps", "6", "--warmup", "2", "--bootstraps", "3", "--cells", "4", "--no-cpu-baseline", "--force-dist"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800, env=env)
