@@ -135,7 +135,7 @@ def build_microbench(force: bool = False) -> list:
     stream of scripts/collect_profiles.sh, the atomics / LDS / gather microbenchmarks).  Built in-tree
     like the library, so they travel to the GPU box; the binaries are git-ignored."""
     out = []
-    for name in ("stream", "atomics"):
+    for name in ("stream", "atomics", "lds_atomics"):
         src, exe = os.path.join(MICROBENCH, name + ".hip"), os.path.join(MICROBENCH, name)
         if force or not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
             subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", src, "-o", exe])
