@@ -1153,3 +1153,28 @@ def test_batched_bootstrap_with_mostly_remote_alignments():
         want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=80, conv_thresh=1e-3)
         assert abs(infos[b].niter - wi.niter) <= 1
         assert_counts_close(out[b], want, R, T, RTOL if infos[b].niter != wi.niter else 1e-8, f"replicate {b}")
+
+
+def test_host_store_uploads_again_when_the_reference_would_see_new_data():
+    """The reference mutates the store between calls (normalize_read_probs fills coverage_probabilities,
+    bulk.rs:103-108; model_coverage selects whether em reads them, em.rs:108).  The host mirror keeps one
+    resident copy per store and must re-make it when either changes, and reject a bootstrap init vector of
+    the wrong length before it reaches the device."""
+    st = synth.make_store(30_000, 2_000, seed=91, coverage=True)
+    store = InMemoryAlignmentStore.from_arrays(st.row_ptr, st.tid, st.as_prob, None, model_coverage=False)
+    txps = [oarfish_amd.TranscriptInfo.with_len(1000)] * st.n_txps
+    emi = oarfish_amd.EMInfo(eq_map=store, txp_info=txps, max_iter=80, convergence_thresh=0.0)
+    plain = oarfish_amd.em(emi, 1)
+    store.coverage_probabilities = st.cov_prob            # what normalize_read_probs assigns (:71)
+    store.filter_opts.model_coverage = True
+    with_cov = oarfish_amd.em(emi, 1)
+    o_plain = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    o_cov = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    assert_counts_close(plain, c_oracle.do_em(o_plain, max_iter=80, conv_thresh=0.0)[0], st.n_reads, st.n_txps, 1e-8, "plain")
+    assert_counts_close(with_cov, c_oracle.do_em(o_cov, max_iter=80, conv_thresh=0.0)[0], st.n_reads, st.n_txps, 1e-8, "coverage")
+    assert np.max(np.abs(with_cov - plain)) > 1e-3        # the column really changed the answer
+    store.filter_opts.model_coverage = False
+    assert_counts_close(oarfish_amd.em(emi, 1), plain, st.n_reads, st.n_txps, 1e-9, "switched back")
+    with pytest.raises(ValueError):
+        store.device_store(st.n_txps).bootstrap(2, init=np.ones(st.n_txps - 1))
+    store.invalidate_device()
