@@ -106,7 +106,7 @@ void oem_store_destroy(oem_store *store);
 typedef enum {
     OEM_OPT_BATCH_BOOTSTRAP = 1, /* value 1 (default): oem_bootstrap runs its replicates in batches that share
                                     each pass over the matrix (4 per pass, two such chains side by side on their
-                                    own streams) when it can (f32 weights, multiplicities < 256); 0: one per pass */
+                                    own streams) when it can (narrow window cap, multiplicities < 256); 0: one per pass */
     OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2 /* value b0 (default 0): replicate k of the next oem_bootstrap calls
                                     draws the device resample of global replica b0 + k.  Lets N processes
                                     that each hold the whole store split one set of replicates with no
@@ -330,7 +330,7 @@ int oem_time_em_iters(oem_store *store, uint32_t n_iters, float *out_ms);
  * timed with HIP events on the store's stream.  out_avg_ms = milliseconds per batched pass;
  * out_slots = replicates served by one pass; out_algorithmic_bytes = SURVEY.md section 8d's bytes
  * of one batched pass (matrix once, row weights + theta/counts per replicate).  OEM_ERR_STATE when
- * the store runs its bootstraps one per pass (f64 weights, wide windows, no tiled layout). */
+ * the store runs its bootstraps one per pass (wide windows, no tiled layout). */
 int oem_time_bootstrap_passes(oem_store *store, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
                               uint64_t *out_algorithmic_bytes);
 

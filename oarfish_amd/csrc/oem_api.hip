@@ -276,10 +276,10 @@ int ensure_batch(oem_store *s, int chain)
     return OEM_OK;
 }
 
-// The batch kernel takes f32 weights, narrow windows and byte multiplicities.
+// The batch kernel takes narrow windows and byte multiplicities (f32 or f64 weights).
 bool can_batch(const oem_store *s)
 {
-    return s->tiled.present && !s->csr.w_is_f64 && s->tiled.n_tiles > 0 && s->tiled.win_cap <= kWin;
+    return s->tiled.present && s->tiled.n_tiles > 0 && s->tiled.win_cap <= kWin;
 }
 
 // A decision that selects which collectives a row-sharded run issues must be the same on every

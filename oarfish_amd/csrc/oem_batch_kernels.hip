@@ -54,8 +54,9 @@ __device__ __forceinline__ double *lds_at_b(double *base, uint32_t byte_off)
     return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
+template <typename WT>
 struct SliceRegsB {
-    float w[kBCh];
+    WT w[kBCh];
     uint32_t c[kBCh / 2];
 };
 
@@ -65,8 +66,8 @@ __device__ __forceinline__ T ld_stream_b(const T *p)
     return kNT ? __builtin_nontemporal_load(p) : *p; // see ld_stream in oem_tile_kernels.hip
 }
 
-template <bool kNT>
-__device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restrict__ wbase,
+template <bool kNT, typename WT>
+__device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__restrict__ wbase,
                                              const uint32_t *__restrict__ cbase, uint32_t lane,
                                              uint32_t width)
 {
@@ -77,24 +78,25 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB &r, const float *__restr
             r.w[2 * g + 1] = ld_stream_b<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
             r.c[g] = ld_stream_b<kNT>(&cbase[g * 64 + lane]);
         } else {
-            r.w[2 * g] = 0.f;
-            r.w[2 * g + 1] = 0.f;
+            r.w[2 * g] = (WT)0;
+            r.w[2 * g + 1] = (WT)0;
             r.c[g] = 0u;
         }
     }
     // the second element of the last pair of an odd-width slice belongs to the next read
 #pragma unroll
     for (int k = 1; k < kBCh; k += 2)
-        if ((uint32_t)k >= width) r.w[k] = 0.f;
+        if ((uint32_t)k >= width) r.w[k] = (WT)0;
 }
 
 // LDS layouts of one epoch (b = slot inside the epoch, c = window entry, r = read of the tile):
 //   theta_l, cnt_l : [c][b]  byte (c * kEB + b) * 8 = code * kEB + b * 8   (code = 8 c, as stored)
 //   den_l          : [b][r]  remote part of the denominators, then c_ib / denom_ib
-template <bool kNT>
+// WT = float (as_prob alone: exact) or double (as_prob * cov_prob, the coverage model: em.rs:107-111)
+template <bool kNT, typename WT>
 __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
-    const float *__restrict__ w, const uint32_t *__restrict__ r_tid, const float *__restrict__ r_w,
+    const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
     double *__restrict__ queue /* [kB][n_remote] */, uint64_t n_remote,
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
@@ -138,16 +140,16 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     }
 
     // ---- the tile's matrix data, loaded once and kept in registers over all epochs ----------
-    SliceRegsB R[kPerWave];
+    SliceRegsB<WT> R[kPerWave];
 #pragma unroll
     for (uint32_t q = 0; q < kPerWave; ++q)
-        load_slice_b<kNT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+        load_slice_b<kNT, WT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
     uint32_t rt[kRemE], rrow[kRemE], rslot[kRemE];
-    float rw[kRemE];
+    WT rw[kRemE];
 #pragma unroll
     for (int k = 0; k < kRemE; ++k) {
         const uint32_t i = tx + k * kTileThreadsE;
-        rt[k] = 0; rw[k] = 0.f; rrow[k] = 0; rslot[k] = 0;
+        rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0;
         if (i < td.remote_cnt) {
             const uint32_t o = td.remote_begin + i;
             rt[k] = ld_stream_b<kNT>(&r_tid[o]);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         for (uint32_t q = 0; q < kPerWave; ++q) {
             const uint32_t s = wave + kWaves * q;
             if (s >= td.n_slices) continue;
-            SliceRegsB cur;
+            SliceRegsB<WT> cur;
             uint32_t width = wid[0], mq = mult[0], wo = woff[0], co = coff[0];
 #pragma unroll
             for (int k = 0; k < kBCh; ++k) cur.w[k] = R[0].w[k];
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                     for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[qq].c[k];
                 }
             const uint32_t rl = s * 64 + lane;
-            const float *wbase = w + (size_t)wo * 64;
+            const WT *wbase = w + (size_t)wo * 64;
             const uint32_t *cbase = codes + (size_t)co * 64;
             double denom[kEB];
 #pragma unroll
@@ -495,16 +497,22 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
-    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * 6 + t.n_remote * 14;
+    const bool f64w = s->csr.w_is_f64;
+    const uint64_t wsz = f64w ? 8 : 4;
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + 10);
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
-    if (nt)
-        hipLaunchKernelGGL((k_em_tile_e<true>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,
-                           (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
-                           t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
-    else
-        hipLaunchKernelGGL((k_em_tile_e<false>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,
-                           (const float *)t.w32, t.r_tid, (const float *)t.r_w32, t.r_row, t.r_slot, bb.queue,
-                           t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w);
+#define OEM_LAUNCH_TILE_E(NT, WT, W, RW)                                                                              \
+    hipLaunchKernelGGL((k_em_tile_e<NT, WT>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,    \
+                       (const WT *)W, t.r_tid, (const WT *)RW, t.r_row, t.r_slot, bb.queue, t.n_remote, bb.theta,      \
+                       bb.cnt, bb.state, bb.row_w)
+    if (f64w) {
+        if (nt) OEM_LAUNCH_TILE_E(true, double, t.w64, t.r_w64);
+        else OEM_LAUNCH_TILE_E(false, double, t.w64, t.r_w64);
+    } else {
+        if (nt) OEM_LAUNCH_TILE_E(true, float, t.w32, t.r_w32);
+        else OEM_LAUNCH_TILE_E(false, float, t.w32, t.r_w32);
+    }
+#undef OEM_LAUNCH_TILE_E
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);

@@ -1114,16 +1114,17 @@ def test_batched_bootstrap_fuzz_random_shapes_match_oracle(seed):
     spread = int(rng.choice([1, 10, 400, max(T, 1)]))
     tid = ((np.repeat(rng.integers(0, T, size=R), lens) + rng.integers(0, spread, size=nnz)) % T).astype(np.uint32)
     p = np.exp(-rng.integers(0, 40, size=nnz) / 5.0).astype(np.float32)
+    cov = rng.uniform(1e-3, 1.0, size=nnz) if seed % 3 == 0 else None      # f64 weights: the coverage model's column
     n_boot = 11
     W = rng.poisson(1.0, size=(n_boot, R)).astype(np.uint32)
     W[2] = 0                                            # a resample that drew nothing (degenerate, but legal input)
     if R > 3:
         W[4, :3] = 255                                  # the largest multiplicity the batch takes
         W[7, 1] = 256                                   # one more: this replicate goes to the one-per-pass path
-    o = c_oracle.Store(rp, tid, p, None, T)
-    with DeviceStore(rp, tid, p, None, T) as d:
+    o = c_oracle.Store(rp, tid, p, cov, T)
+    with DeviceStore(rp, tid, p, cov, T) as d:
         out, infos = d.bootstrap(n_boot, row_w_all=W, max_iter=120, conv_thresh=1e-3)
-    what = f"seed {seed}: R={R} T={T} maxk={maxk} spread={spread}"
+    what = f"seed {seed}: R={R} T={T} maxk={maxk} spread={spread} cov={cov is not None}"
     for b in range(n_boot):
         want, wi = c_oracle.do_em(o, row_w=W[b], max_iter=120, conv_thresh=1e-3)
         assert abs(infos[b].niter - wi.niter) <= 1, (what, b, infos[b], wi)
