@@ -9,8 +9,10 @@
 // What amortises and what does not.  The matrix streams (weights, window codes, remote
 // records: ~0.65 GB at 10 M reads) and the L2 requests of the remote theta gathers are paid
 // once per pass whatever the number of slots: theta is laid out [transcript][slot], so the
-// kEB = 4 slots of an epoch sit in one 32-byte piece of a 64-byte line.  The per-slot work
-// (LDS traffic of the local alignments, 8 bytes of queue per remote alignment) is not shared.
+// kEB = 4 slots of an epoch sit in one 32-byte piece of a transcript's kBatch * 8 bytes.  The
+// per-slot work (LDS traffic of the local alignments, 8 bytes of queue per remote alignment) is
+// not shared, and measured it is what the pass costs: ~150 us per slot at 4, 8 or 16 slots
+// (profiles/r02_notes.md) -- hence kBatch = 4 (one epoch) and two chains, which overlap.
 //
 // k_em_tile_e: one workgroup per tile, the tile's matrix data loaded ONCE into registers,
 // then kE "epochs" of kEB = 4 slots each run over it: per epoch the theta window, the count
