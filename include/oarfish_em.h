@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define OEM_ABI_VERSION 1
+/* 2: oem_time_bootstrap_passes, oem_store_opts.layout_build (was reserved[0]), the peer-to-peer
+ *    communicator entry points (oem_comm_ipc_*); version 1 callers keep working (additions only). */
+#define OEM_ABI_VERSION 2
 
 typedef enum {
     OEM_OK = 0,
@@ -333,6 +335,14 @@ int oem_time_em_iters(oem_store *store, uint32_t n_iters, float *out_ms);
  * the store runs its bootstraps one per pass (wide windows, no tiled layout). */
 int oem_time_bootstrap_passes(oem_store *store, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
                               uint64_t *out_algorithmic_bytes);
+
+/* Device time of the batched EM loops of this thread's LAST oem_em_run_cells call: milliseconds between
+ * HIP events recorded on the group's stream right before the first and right after the last pass of
+ * every batched group (upload, layout build and read-back excluded), and the batched passes launched.
+ * Together with the per-cell n_passes of `infos` this gives bench.py the roofline of the per-cell leg:
+ * bytes = sum over cells of n_passes * (nnz_c * 8 + (R_c + 1) * 4 + 2 * T * 8).  Zero when every group
+ * took the cell-by-cell fallback. */
+int oem_cells_last_timing(float *out_loop_ms, uint64_t *out_batched_passes);
 
 #ifdef __cplusplus
 }

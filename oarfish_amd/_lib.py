@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
     "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_store_attach_comm",
-    "oem_time_m_step", "oem_time_em_iters", "oem_time_bootstrap_passes",
+    "oem_time_m_step", "oem_time_em_iters", "oem_time_bootstrap_passes", "oem_cells_last_timing",
 ]
 
 
@@ -136,6 +136,7 @@ def _load(path: str) -> C.CDLL:
     L.oem_time_m_step.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_time_em_iters.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_time_bootstrap_passes.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(u64)]
+    L.oem_cells_last_timing.argtypes = [C.POINTER(C.c_float), C.POINTER(u64)]
     for name in ABI_SYMBOLS:
         getattr(L, name)
     return L

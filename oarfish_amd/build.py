@@ -91,7 +91,7 @@ def _compile(src: str, testing: bool, verbose: bool) -> None:
     cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src)]
     if testing:
         cmd.append("-DOEM_TESTING")
-    if os.environ.get("OEM_KBATCH"):  # experiments only: slots of the batched bootstrap (default 8)
+    if os.environ.get("OEM_KBATCH"):  # experiments only: slots of one chain of the batched bootstrap (default 4)
         cmd.append("-DOEM_KBATCH=" + os.environ["OEM_KBATCH"])
     out = _obj_path(src, testing)
     cmd += ["-o", out + ".tmp"]
@@ -101,8 +101,35 @@ def _compile(src: str, testing: bool, verbose: bool) -> None:
     os.replace(out + ".tmp", out)
 
 
-def _link(objs, out: str, verbose: bool) -> None:
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", out + ".tmp", "-ldl", "-lpthread"]
+TESTING_HOOKS = ["oem_debug_layout_hash", "oem_debug_local_comm_create", "oem_test_reldiff_stress", "oem_debug_knob"]
+
+
+def header_symbols() -> list:
+    """Every function include/oarfish_em.h declares, in declaration order."""
+    import re
+    src = open(os.path.join(INCLUDE, "oarfish_em.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = []
+    for name in re.findall(r"\b(oem_[a-z0-9_]+)\s*\(", src):
+        if name not in out:
+            out.append(name)
+    return out
+
+
+def _version_script(path: str, symbols) -> str:
+    """The dynamic symbol table of a library is exactly `symbols`: oem:: internals, rocPRIM
+    instantiations and kernel stubs stay local (nm -D shows the header's entry points and nothing else)."""
+    txt = "{\n  global:\n" + "".join(f"    {s};\n" for s in symbols) + "  local:\n    *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != txt:
+        with open(path, "w") as f:
+            f.write(txt)
+    return path
+
+
+def _link(objs, out: str, verbose: bool, exports) -> None:
+    vs = _version_script(os.path.join(OBJ, os.path.basename(out) + ".map"), exports)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-Wl,--version-script=" + vs,
+           *objs, "-o", out + ".tmp", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -122,8 +149,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(lambda j: _compile(j[0], j[1], verbose), todo))
     product = [_obj_path(s, False) for s in SOURCES]
     testing = [_obj_path(s, s in TESTING_VARIANTS) for s in SOURCES] + [_obj_path(s, True) for s in TESTING_ONLY]
-    _link(product, LIB_PATH, verbose)
-    _link(testing, TESTING_LIB_PATH, verbose)
+    _link(product, LIB_PATH, verbose, header_symbols())
+    _link(testing, TESTING_LIB_PATH, verbose, header_symbols() + TESTING_HOOKS)
     return LIB_PATH
 
 

@@ -270,6 +270,12 @@ int ensure_batch(oem_store *s, int chain)
     OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 16, &s->hbm_bytes));
     OEM_HIP(hipMemsetAsync(b.row_w, 0, (size_t)s->tiled.n_rows * kBatch + 16, b.stream));
+    // a slot that is never handed a replicate (n_boot < kBatch, the tail of a chain) is still swept by the
+    // tile kernel's four-slot epoch: its columns must hold zeros, not whatever hipMalloc returned
+    OEM_HIP(hipMemsetAsync(b.theta, 0, sizeof(double) * T * kBatch, b.stream));
+    OEM_HIP(hipMemsetAsync(b.cnt, 0, sizeof(double) * 2 * T * kBatch, b.stream));
+    OEM_HIP(hipMemsetAsync(b.out, 0, sizeof(double) * T * kBatch, b.stream));
+    OEM_HIP(hipMemsetAsync(b.queue, 0, sizeof(double) * (size_t)s->tiled.n_remote * kBatch, b.stream));
     OEM_TRY(dev_alloc(&b.overflow, 1, &s->hbm_bytes));
     OEM_HIP(hipHostMalloc((void **)&b.h_state, sizeof(BatchState) * kBatch, hipHostMallocDefault));
     OEM_HIP(hipHostMalloc((void **)&b.h_out, sizeof(double) * T * kBatch, hipHostMallocDefault));
@@ -438,13 +444,24 @@ int run_bootstrap_rolling(oem_store *s, uint32_t n_boot, uint64_t seed, const ui
             rcs[c] = run_bootstrap_chain(s, c, &job);
         } catch (const std::exception &e) {
             rcs[c] = fail(OEM_ERR_OOM, "bootstrap chain: %s", e.what());
+        } catch (...) {
+            rcs[c] = fail(OEM_ERR_STATE, "bootstrap chain: unknown C++ exception");
         }
         if (rcs[c] != OEM_OK) errs[c] = t_err; // t_err is thread-local
     };
-    std::vector<std::thread> th;
-    for (int c = 1; c < n_chains; ++c) th.emplace_back(body, c);
+    // (a std::thread constructor that throws must not leave joinable threads behind: std::terminate)
+    struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+    } pool;
+    int started = 1;
+    try {
+        for (int c = 1; c < n_chains; ++c) { pool.th.emplace_back(body, c); ++started; }
+    } catch (...) { // the chains that did start (and chain 0 below) take all the replicates
+    }
     body(0);
-    for (auto &t : th) t.join();
+    for (auto &t : pool.th) t.join();
+    n_chains = started;
     for (int c = 0; c < n_chains; ++c)
         if (rcs[c] != OEM_OK) return fail(rcs[c], "%s", errs[c].c_str());
     *fallback = job.fallback;
@@ -985,6 +1002,11 @@ extern "C" int oem_bootstrap(oem_store *s, uint32_t n_boot, uint64_t seed, const
 namespace oem {
 namespace {
 
+// What the last oem_em_run_cells call of this thread spent in its batched EM loops (HIP events on the
+// group's stream around the loop), for oem_cells_last_timing.
+thread_local double t_cells_loop_ms = 0.0;
+thread_local uint64_t t_cells_batched_passes = 0;
+
 // All cells in one store over the concatenated transcript space; every pass serves every
 // unfinished cell.  Returns *used = false (nothing done) when the batch form does not apply.
 int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint64_t *row_ptr,
@@ -1055,6 +1077,14 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             const bool fused_fold = s->tiled.n_remote > 0 && s->tiled.n_buckets > 0 && knob("OEM_CELLS_FUSED_FOLD", 1) != 0;
             uint64_t launched = 0;
             uint32_t unfinished = n_cells;
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess ||
+                hipEventRecord(ev0, s->stream) != hipSuccess) {
+                if (ev0) hipEventDestroy(ev0);
+                if (ev1) hipEventDestroy(ev1);
+                rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: event set-up failed");
+                break;
+            }
             while (launched < total && unfinished) {
                 uint64_t chunk = launched == 0 ? 53 : 16;
                 if (chunk > total - launched) chunk = total - launched;
@@ -1075,6 +1105,15 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
                     break;
                 }
             }
+            if (rc2 == OEM_OK && hipEventRecord(ev1, s->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                    t_cells_loop_ms += ms;
+                    t_cells_batched_passes += launched;
+                }
+            }
+            hipEventDestroy(ev0);
+            hipEventDestroy(ev1);
             if (rc2 != OEM_OK) break;
             tm.lap("cells: EM loop");
             if (hipMemcpy(out, mb.out, sizeof(double) * total_txps, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1169,7 +1208,13 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         if (cell_row_off[c + 1] < cell_row_off[c])
             return fail(OEM_ERR_ARG, "oem_em_run_cells: cell_row_off not non-decreasing at cell %u", c);
     if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_em_run_cells: tid/as_prob is NULL");
+    t_cells_loop_ms = 0.0;
+    t_cells_batched_passes = 0;
     OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps)); // all cells at once, on several host threads
+    // a read with a NaN coverage probability is dropped (em.rs:115), on every path below: the batched
+    // groups create their stores directly, not through oem_store_create
+    std::vector<double> cov_fixed;
+    if (cov_prob && zero_nan_rows(row_ptr, cov_prob, n_reads, nnz, &cov_fixed)) cov_prob = cov_fixed.data();
 
     // Cells are independent problems, so a large experiment is cut into groups of consecutive cells
     // that bound the batched store (transcript space < 2^32, <= 2^30 alignments, and the layout
@@ -1284,6 +1329,15 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     OEM_API_END("oem_time_em_iters")
 }
 
+extern "C" int oem_cells_last_timing(float *out_loop_ms, uint64_t *out_batched_passes)
+{
+    OEM_API_BEGIN
+    if (out_loop_ms) *out_loop_ms = (float)t_cells_loop_ms;
+    if (out_batched_passes) *out_batched_passes = t_cells_batched_passes;
+    return OEM_OK;
+    OEM_API_END("oem_cells_last_timing")
+}
+
 extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
                                          uint64_t *out_algorithmic_bytes)
 {
@@ -1327,10 +1381,10 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
     *out_avg_ms = ms / (float)n_passes;
     if (out_slots) *out_slots = kBatch;
     if (out_algorithmic_bytes) {
-        // the matrix once per batched pass (nnz * 8 + row pointers), and per replicate the
+        // the matrix once per batched pass (nnz * (4 + 4|8) + row pointers), and per replicate the
         // row weights (R * 4) and theta read / counts written once per transcript (2 * T * 8)
         const DeviceCsr &m = s->csr;
-        *out_algorithmic_bytes = m.nnz * 8 + (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) +
+        *out_algorithmic_bytes = m.nnz * (4 + (m.w_is_f64 ? 8 : 4)) + (m.n_reads + 1) * (m.wide_ptr ? 8 : 4) +
                                  (uint64_t)kBatch * (m.n_reads * 4 + 2ull * m.n_txps * 8);
     }
     return OEM_OK;

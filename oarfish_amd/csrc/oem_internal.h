@@ -190,7 +190,7 @@ struct oem_store {
     oem::BatchBuffers batch[oem::kChains]; // lazily allocated by the batched bootstrap
     oem::MultiBuffers multi;             // per-cell batches
     uint32_t bootstrap_first_replica = 0; // OEM_OPT_BOOTSTRAP_FIRST_REPLICA
-    bool batch_bootstrap = true;         // OEM_OPT_BATCH_BOOTSTRAP (2 replicates per pass when applicable)
+    bool batch_bootstrap = true;         // OEM_OPT_BATCH_BOOTSTRAP (kChains chains of kBatch replicates per pass when applicable)
     // multi-GPU
     oem::Comm *comm = nullptr;
     uint64_t global_n_reads = 0;

@@ -57,6 +57,10 @@ extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out
 }
 
 
+// Test hook: what oem::knob() returns in THIS library (the environment variable in the test-only build; the
+// product's knob() is compiled without getenv and returns its default, checked on the object file).
+extern "C" long oem_debug_knob(const char *name, long dflt) { return oem::knob(name, dflt); }
+
 // ---------------------------------------------------------------------------
 // Stress test of k_reldiff_swap_clear's last-block election (oem_kernels.hip): the stopping
 // decision of every EM run (em.rs:194-218) is taken by the workgroup that draws the last ticket,

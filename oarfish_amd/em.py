@@ -92,3 +92,11 @@ def em_cells(cell_row_off: Sequence[int], boundaries, ref_ids, as_probabilities,
         convergence_thresh, out.ctypes.data, C.addressof(infos)))
     return out, [RunInfo(i.niter, i.n_passes, bool(i.converged), i.rel_diff)
                  for i in list(infos)[:n_cells]]
+
+
+def cells_last_timing():
+    """(device milliseconds of the batched EM loops, batched passes launched) of this thread's last
+    ``em_cells`` call -- oem_cells_last_timing; bench.py's per-cell roofline."""
+    ms, n = C.c_float(0), C.c_uint64(0)
+    _lib.check(_lib.lib().oem_cells_last_timing(C.byref(ms), C.byref(n)))
+    return float(ms.value), int(n.value)

@@ -315,10 +315,12 @@ class InMemoryAlignmentStore:
         # arrays it was made from and by model_coverage, and re-made when any of them is replaced.
         # (In-place writes into an array after its upload need an explicit invalidate_device().)
         key = (int(device), int(n_txps))
-        stamp = (id(self.boundaries), id(self.alignments), id(self.as_probabilities),
-                 None if cov is None else id(cov), bool(self.filter_opts.model_coverage))
+        # the stamp holds the arrays themselves (compared with `is`): an id() alone can be reused by a
+        # later array once the first one is freed, and a stale resident copy would then look current
+        stamp = (self.boundaries, self.alignments, self.as_probabilities, cov, bool(self.filter_opts.model_coverage))
         hit = self._dev.get(key)
-        if hit is not None and hit[0] != stamp:
+        if hit is not None and not (len(hit[0]) == len(stamp) and
+                                    all(a is b for a, b in zip(hit[0][:4], stamp[:4])) and hit[0][4] == stamp[4]):
             hit[1].close()
             hit = None
         if hit is None:

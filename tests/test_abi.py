@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/oarfish_em.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.oem_abi_version() == 1
+    assert L.oem_abi_version() == 2
 
 
 def test_no_torch_types_in_abi():
@@ -86,25 +86,42 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in txt.replace("SURVEY", ""), f"{f} mentions the oracle"
 
 
-def test_product_library_carries_no_test_hooks_or_env_knobs(monkeypatch):
-    """liboarfish_em.so exports exactly the header's entry points: the debug / test hooks and the
-    environment-driven knobs exist only in liboarfish_em_testing.so (built with -DOEM_TESTING)."""
+def _exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_product_library_exports_exactly_the_header(monkeypatch):
+    """nm -D of liboarfish_em.so is the header's entry points and NOTHING else (no oem:: internals, no
+    rocPRIM instantiations: the link uses a version script made from the header); the debug / test
+    hooks and the environment-driven knobs exist only in liboarfish_em_testing.so (-DOEM_TESTING)."""
     import subprocess
     from oarfish_amd import build as _b
 
-    def exported(path):
-        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
-        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
-
-    prod, test = exported(_b.LIB_PATH), exported(_b.TESTING_LIB_PATH)
-    c_abi = {s for s in prod if s.startswith("oem_")}
-    assert c_abi == set(_header_symbols()), sorted(c_abi ^ set(_header_symbols()))
-    hooks = {"oem_debug_layout_hash", "oem_debug_local_comm_create", "oem_test_reldiff_stress"}
-    assert hooks <= test and not (hooks & prod)
-    # the knob function of the product ignores the environment (oem_knobs.cpp without OEM_TESTING)
+    prod, test = _exported(_b.LIB_PATH), _exported(_b.TESTING_LIB_PATH)
+    assert prod == set(_header_symbols()), sorted(prod ^ set(_header_symbols()))
+    hooks = set(_b.TESTING_HOOKS)
+    assert test == set(_header_symbols()) | hooks, sorted(test ^ (set(_header_symbols()) | hooks))
+    # the product's knob() never reads the environment: its object file does not even reference getenv
+    def undefined(obj):
+        out = subprocess.check_output(["nm", "-u", obj], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    obj = os.path.join(_b.OBJ, "oem_knobs.o")
+    assert "getenv" not in undefined(obj)
+    assert "getenv" in undefined(os.path.join(_b.OBJ, "oem_knobs.testing.o"))
     monkeypatch.setenv("OEM_SELFTEST_KNOB", "7")
-    knob = "_ZN3oem4knobEPKcl"
-    for L, want in ((C.CDLL(_b.LIB_PATH), 3), (C.CDLL(_b.TESTING_LIB_PATH), 7)):
-        fn = getattr(L, knob)
-        fn.restype, fn.argtypes = C.c_long, [C.c_char_p, C.c_long]
-        assert fn(b"OEM_SELFTEST_KNOB", 3) == want
+    T = _lib.testing_lib()
+    T.oem_debug_knob.restype, T.oem_debug_knob.argtypes = C.c_long, [C.c_char_p, C.c_long]
+    assert T.oem_debug_knob(b"OEM_SELFTEST_KNOB", 3) == 7
+    assert not hasattr(_lib.lib(), "oem_debug_knob")
+
+
+def test_header_is_strict_c99(tmp_path):
+    """The boundary is a C ABI: include/oarfish_em.h must compile as C99 with no C++ or HIP in sight."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "oarfish_em.h"\nint main(void) { oem_run_info i; oem_store_opts o; (void)i; (void)o; '
+                   'return OEM_ABI_VERSION == oem_abi_version() ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])

@@ -28,7 +28,7 @@ def _orc(g):
 def test_extension_is_loaded_and_device_present():
     from oarfish_amd import _lib
     assert _lib.device_count() >= 1
-    assert _lib.lib().oem_abi_version() == 1
+    assert _lib.lib().oem_abi_version() == 2
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -206,6 +206,41 @@ def test_cells_match_per_cell_oracle():
         want, wi = c_oracle.do_em(o, max_iter=300, conv_thresh=1e-3, min_iter_gate=50)
         assert abs(infos[c].niter - wi.niter) <= 1
         assert_counts_close(out[c], want, r1 - r0, T, RTOL, f"cell {c}")
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_cells_with_nan_coverage_drop_the_read_on_every_path(serial, monkeypatch):
+    """single_cell.rs:132-137 with model_coverage: a zero-span alignment leaves a NaN in the read's
+    coverage column (normalize_probability.rs:58), the reference's `denom > 1e-30` test then fails and the
+    read contributes nothing (em.rs:115).  The batched per-cell path builds its stores without going through
+    oem_store_create, the cell-by-cell fallback goes through it: both must drop exactly those reads."""
+    from oarfish_amd import _lib
+    n_cells, T = 5, 400
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, 2_500, T, seed=21)
+    rng = np.random.default_rng(5)
+    cov = rng.uniform(0.05, 1.0, len(tid))
+    n_reads = len(row_ptr) - 1
+    bad = rng.choice(n_reads, 40, replace=False)
+    for r in bad:   # one NaN somewhere in the read, as normalize_read_probs leaves it
+        a0, a1 = int(row_ptr[r]), int(row_ptr[r + 1])
+        cov[a0 + int(rng.integers(0, a1 - a0))] = np.nan
+    if serial:   # the knob that forces the cell-by-cell fallback exists only in the test-only library
+        monkeypatch.setenv("OEM_SERIAL_CELLS", "1")
+        with _lib.testing():
+            out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, cov, T, max_iter=300, convergence_thresh=1e-3)
+    else:
+        out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, cov, T, max_iter=300, convergence_thresh=1e-3)
+    assert np.all(np.isfinite(out))
+    for c in range(n_cells):
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        o = c_oracle.Store(row_ptr[r0:r1 + 1] - row_ptr[r0], tid[a0:a1], p[a0:a1], cov[a0:a1], T)
+        want, wi = c_oracle.do_em(o, max_iter=300, conv_thresh=1e-3, min_iter_gate=50)
+        dropped = int(((bad >= r0) & (bad < r1)).sum())
+        assert np.all(np.isfinite(want)) and abs(want.sum() - (r1 - r0 - dropped)) < 1e-9 * (r1 - r0)
+        assert abs(out[c].sum() - (r1 - r0 - dropped)) < 1e-9 * (r1 - r0)
+        assert abs(infos[c].niter - wi.niter) <= 1
+        assert_counts_close(out[c], want, r1 - r0, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"cell {c}")
 
 
 def _layout_hash(row_ptr, tid, p, cov, T, problem_size=0, win_cap=0, host_build=False):
@@ -776,7 +811,7 @@ def test_full_size_c3_properties():
         assert np.all(full >= u - 1e-6) and np.all(full <= t + 1e-6)
         w = d.bootstrap_weights(3, 0)
         assert int(w.sum()) == st.n_reads and abs(w.var() - 1.0) < 0.01
-        # The batched bootstrap at full size (k_em_tile_e: 8 slots per pass, two epochs): a short fixed
+        # The batched bootstrap at full size (k_em_tile_e: 4 slots per pass, one epoch; two chains): a short fixed
         # number of iterations of a drawn resample and of the identity resample against the oracle, ...
         W = np.stack([w, np.ones(st.n_reads, dtype=np.uint32), d.bootstrap_weights(3, 2)])
         bout, binfo = d.bootstrap(3, row_w_all=W, max_iter=8, conv_thresh=0.0)
@@ -792,6 +827,28 @@ def test_full_size_c3_properties():
         assert_counts_close(ident[0], point, st.n_reads, st.n_txps, RTOL if iinfo[0].niter != pinfo.niter else 1e-8,
                             "identity resample through the batch path")
         assert abs(ident[1].sum() - st.n_reads) < 1e-7 * st.n_reads           # a resample keeps the read count
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_c3_to_convergence_matches_oracle_under_both_gates():
+    """BASELINE configs[2] as stated: the 10 M x 200 k store, the reference's defaults (max_iter 1000,
+    conv_thresh 1e-3), EM TO CONVERGENCE, under the gate of em::em (niter > 50, em.rs:212) and of em::em_par
+    (niter > 1, em.rs:399), every transcript against the serial oracle (do_em, ~0.15 s per pass: minutes).
+    One oracle run serves both gates: it runs with gate 1, and when it stops at niter > 51 the condition
+    `rel_diff < thresh` was false at every earlier iteration, so the gate-50 loop walks the identical
+    trajectory and stops at the same iteration (the stopping rule differs in nothing else)."""
+    st = synth.make_config("c3")
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        got = {gate: d.em_run(None, 1000, 1e-3, gate) for gate in (50, 1)}
+    want, wi = c_oracle.do_em(o, max_iter=1000, conv_thresh=1e-3, min_iter_gate=1)
+    assert wi.converged and wi.niter > 51, wi      # else the oracle must be run once per gate
+    for gate, (cnt, info) in got.items():
+        assert abs(info.niter - wi.niter) <= 1, (gate, info, wi)
+        assert info.converged and info.n_passes == info.niter + 2
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL if info.niter != wi.niter else 1e-8,
+                            f"c3 to convergence, gate {gate}")
+        assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads
 
 
 @pytest.mark.parametrize("name", ["c2"])
