@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* 2: oem_time_bootstrap_passes, oem_store_opts.layout_build (was reserved[0]), the peer-to-peer
- *    communicator entry points (oem_comm_ipc_*); version 1 callers keep working (additions only). */
+ *    communicator entry points (oem_comm_p2p_*); version 1 callers keep working (additions only). */
 #define OEM_ABI_VERSION 2
 
 typedef enum {
@@ -304,6 +304,28 @@ int oem_comm_unique_id(void *out_id /* OEM_UNIQUE_ID_BYTES */);
 int oem_comm_create(const void *unique_id, int rank, int n_ranks, int device, oem_comm **out);
 void oem_comm_destroy(oem_comm *comm);
 
+/* The one-shot peer-to-peer exchange (oem_p2p.hip): every rank publishes its partial count vector in a
+ * buffer its peers have mapped (hipIpc memory handles between processes; plain pointers between ranks
+ * that are threads of one process) and sums the N partials itself, in rank order -- bit-identical on
+ * every rank, no ring, no RCCL.  It serves vectors of up to 4 MB (the 1.6 MB count vector of a
+ * 200 k-transcript store is latency-bound; the reference's analogue is the shared Vec<AtomicF64> of
+ * em.rs:338-341); larger exchanges stay with RCCL when the communicator has one.
+ *   oem_comm_create(NULL, rank, n_ranks > 1, ...) makes a communicator without RCCL;
+ *   oem_comm_p2p_export: allocates this rank's exchange buffer for vectors of up to `capacity` doubles
+ *     (n_txps, or 2 * n_txps * 4 to cover the batched bootstrap of a row-sharded store) and writes its
+ *     handle (OEM_P2P_HANDLE_BYTES bytes), which the host gathers over whatever it has (as the unique id);
+ *   oem_comm_p2p_connect: `all_handles` = the n_ranks handles in rank order; maps the peers' buffers.
+ * All ranks must export the same capacity.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only
+ * supports dmabuf IPC.  A rank that waits more than 8 s for a peer fails with OEM_ERR_STATE. */
+#define OEM_P2P_HANDLE_BYTES 128
+int oem_comm_p2p_export(oem_comm *comm, uint64_t capacity, void *out_handle /* OEM_P2P_HANDLE_BYTES */);
+int oem_comm_p2p_connect(oem_comm *comm, const void *all_handles /* n_ranks x OEM_P2P_HANDLE_BYTES */);
+
+/* Collective (every rank, same value).  OEM_COMM_OPT_P2P_MAX_BYTES: largest vector, in bytes, that takes
+ * the peer-to-peer exchange when the communicator also has RCCL (default 4 MB; 0 = always RCCL). */
+typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1 } oem_comm_option;
+int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t value);
+
 /* Declare `store` to be rank-local row shard of a store with
  * `global_n_reads` reads in total (needed for the uniform init, em.rs:154,165).
  * After this, oem_em_run / oem_bootstrap on the shard are collective calls:
@@ -335,6 +357,11 @@ int oem_time_em_iters(oem_store *store, uint32_t n_iters, float *out_ms);
  * the store runs its bootstraps one per pass (wide windows, no tiled layout). */
 int oem_time_bootstrap_passes(oem_store *store, uint32_t n_passes, float *out_avg_ms, uint32_t *out_slots,
                               uint64_t *out_algorithmic_bytes);
+
+/* Collective on a store with an attached communicator: `n_calls` all-reduces of the n_txps count vector
+ * back to back on the store's stream, between HIP events; *out_avg_us = microseconds per all-reduce
+ * (the exchange by itself: peer to peer = publish + reduce kernels, RCCL = ncclAllReduce). */
+int oem_time_allreduce(oem_store *store, uint32_t n_calls, float *out_avg_us);
 
 /* Device time of the batched EM loops of this thread's LAST oem_em_run_cells call: milliseconds between
  * HIP events recorded on the group's stream right before the first and right after the last pass of

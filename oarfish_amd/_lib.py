@@ -20,8 +20,10 @@ OEM_ERR_RCCL = 4
 OEM_ERR_NO_DEVICE = 5
 OEM_ERR_STATE = 6
 OEM_UNIQUE_ID_BYTES = 128
+OEM_P2P_HANDLE_BYTES = 128
 OEM_OPT_BATCH_BOOTSTRAP = 1
 OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2
+OEM_COMM_OPT_P2P_MAX_BYTES = 1
 
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -34,8 +36,10 @@ ABI_SYMBOLS = [
     "oem_m_step", "oem_em_run", "oem_aux_counts", "oem_assignment_probs",
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
-    "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_store_attach_comm",
-    "oem_time_m_step", "oem_time_em_iters", "oem_time_bootstrap_passes", "oem_cells_last_timing",
+    "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_comm_p2p_export", "oem_comm_p2p_connect",
+    "oem_comm_set_option", "oem_store_attach_comm",
+    "oem_time_m_step", "oem_time_em_iters", "oem_time_bootstrap_passes", "oem_time_allreduce",
+    "oem_cells_last_timing",
 ]
 
 
@@ -132,6 +136,10 @@ def _load(path: str) -> C.CDLL:
     L.oem_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.oem_comm_destroy.argtypes = [vp]
     L.oem_comm_destroy.restype = None
+    L.oem_comm_p2p_export.argtypes = [vp, u64, vp]
+    L.oem_comm_p2p_connect.argtypes = [vp, vp]
+    L.oem_comm_set_option.argtypes = [vp, u32, u64]
+    L.oem_time_allreduce.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_store_attach_comm.argtypes = [vp, vp, u64, u64]
     L.oem_time_m_step.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_time_em_iters.argtypes = [vp, u32, C.POINTER(C.c_float)]

@@ -182,12 +182,29 @@ int prepare_row_w(oem_store *s, const RunArgs &a)
     return OEM_OK;
 }
 
+// the per-bucket tickets of k_remote_fold_fin (allocated on first use)
+int ensure_bucket_tickets(oem_store *s)
+{
+    DeviceTiled &t = s->tiled;
+    if (!t.present || t.n_buckets == 0 || t.bucket_arrived) return OEM_OK;
+    OEM_TRY(dev_alloc(&t.bucket_arrived, t.n_buckets, &s->hbm_bytes));
+    OEM_HIP(hipMemsetAsync(t.bucket_arrived, 0, sizeof(uint32_t) * t.n_buckets, s->stream));
+    return OEM_OK;
+}
+
 // one loop iteration on the stream: E/M pass, (all-reduce), rel-diff/swap/clear
 int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
 {
+    // single GPU, tiled store with remote alignments: the fold kernel finishes the iteration itself
+    if (!comm_exchanges(s->comm) && use_tiled(s, a) && can_fuse_fold_reldiff(s) && knob("OEM_FUSED_FOLD", 1) != 0)
+        return launch_em_iteration_tiled_fused(s, s->theta, s->cnt, s->d_state, p, a.d_row_w ? s->tiled.row_w_perm : nullptr);
     OEM_TRY(enqueue_pass(s, a, s->d_state));
-    if (comm_exchanges(s->comm))
-        OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, p.n_txps, s->stream));
+    if (comm_exchanges(s->comm)) {
+        // peer to peer: the sum over the shards happens inside the rel-diff kernel (oem_p2p.hip)
+        if (comm_fuses_reldiff(s->comm, p.n_txps))
+            return comm_reldiff_fused(s->comm, s->theta, s->cnt, s->d_state, p, s->stream);
+        OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, p.n_txps, s->stream, s->d_state));
+    }
     OEM_TRY(launch_reldiff_swap_clear(s, s->theta, s->cnt, s->d_state, p));
     return OEM_OK;
 }
@@ -209,11 +226,15 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
     OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
     std::memset(s->h_state, 0, sizeof(EmState));
     OEM_TRY(prepare_row_w(s, a));
+    OEM_TRY(ensure_bucket_tickets(s));
 
     // The stopping rule cannot fire before niter > gate, so the first look at
     // the device state is due after gate+2 passes; afterwards every `kChunk`.
+    // (with RCCL every launch of a finished run still costs a real all-reduce of zeros, so a row shard
+    // that exchanges through it looks at the state every 4 iterations; the peer-to-peer exchange skips
+    // itself on the device)
     uint64_t launched = 0;
-    constexpr uint64_t kChunk = 16;
+    const uint64_t kChunk = comm_exchange_is_unconditional(s->comm, T) ? 4 : 16;
     while (launched < a.max_iter) {
         uint64_t chunk = launched == 0 ? (uint64_t)a.min_iter_gate + 2 : kChunk; // (a gate of u32::MAX must not wrap)
         if (chunk > a.max_iter - launched) chunk = a.max_iter - launched;
@@ -222,6 +243,7 @@ int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
         launched += chunk;
         OEM_HIP(hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream));
         OEM_HIP(hipStreamSynchronize(s->stream));
+        OEM_TRY(comm_check(s->comm, s->stream));
         if (s->h_state->done) break;
     }
 
@@ -244,6 +266,7 @@ int copy_counts_out(oem_store *s, double *out)
     const uint32_t T = s->csr.n_txps;
     OEM_HIP(hipMemcpyAsync(s->h_pinned, s->cnt, sizeof(double) * T, hipMemcpyDeviceToHost, s->stream));
     OEM_HIP(hipStreamSynchronize(s->stream));
+    OEM_TRY(comm_check(s->comm, s->stream));
     std::memcpy(out, s->h_pinned, sizeof(double) * T);
     return OEM_OK;
 }
@@ -482,7 +505,7 @@ void free_store(oem_store *s)
         oem::DeviceTiled &t = s->tiled;
         hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
         hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
-        hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.queue);
+        hipFree(t.r_slot); hipFree(t.q_dst); hipFree(t.bucket_base); hipFree(t.bucket_arrived); hipFree(t.queue);
         hipFree(t.row_w_perm);
     }
     for (int c = 0; c < oem::kChains; ++c) {
@@ -1257,6 +1280,9 @@ extern "C" int oem_store_attach_comm(oem_store *s, oem_comm *comm, uint64_t glob
         return fail(OEM_ERR_ARG, "oem_store_attach_comm: shard [%llu,+%llu) exceeds %llu reads",
                     (unsigned long long)global_row_offset, (unsigned long long)s->csr.n_reads,
                     (unsigned long long)global_n_reads);
+    if (comm && comm_size(reinterpret_cast<Comm *>(comm)) > 1 && !comm_exchanges(reinterpret_cast<Comm *>(comm)))
+        return fail(OEM_ERR_STATE, "oem_store_attach_comm: a communicator of %d ranks with no backend connected "
+                    "(RCCL unique id, or oem_comm_p2p_export + oem_comm_p2p_connect)", comm_size(reinterpret_cast<Comm *>(comm)));
     std::lock_guard<std::mutex> lk(s->mu);
     s->comm = reinterpret_cast<Comm *>(comm);
     s->global_n_reads = global_n_reads;
@@ -1313,10 +1339,34 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     OEM_TRY(launch_fill(s, s->theta, (double)a.total_reads / (double)T, T));
     OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
     OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
+    OEM_TRY(ensure_bucket_tickets(s));
     hipEvent_t e0, e1;
     OEM_HIP(hipEventCreate(&e0));
     OEM_HIP(hipEventCreate(&e1));
     OEM_HIP(hipEventRecord(e0, s->stream));
+    if (knob("OEM_GRAPH", 0) != 0 && !comm_exchanges(s->comm) && n_iters >= 16) {
+        // experiment (test-only library): chunks of 16 iterations replayed from a hipGraph
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        OEM_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        for (uint32_t k = 0; k < 16; ++k) OEM_TRY(enqueue_iteration(s, a, p));
+        OEM_HIP(hipStreamEndCapture(s->stream, &g));
+        OEM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        OEM_HIP(hipGraphLaunch(ge, s->stream)); // untimed: upload
+        OEM_HIP(hipStreamSynchronize(s->stream));
+        OEM_HIP(hipEventRecord(e0, s->stream));
+        for (uint32_t k = 0; k + 16 <= n_iters; k += 16) OEM_HIP(hipGraphLaunch(ge, s->stream));
+        OEM_HIP(hipEventRecord(e1, s->stream));
+        OEM_HIP(hipEventSynchronize(e1));
+        hipGraphExecDestroy(ge);
+        hipGraphDestroy(g);
+        float gms = 0.f;
+        OEM_HIP(hipEventElapsedTime(&gms, e0, e1));
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        *out_ms = gms * (float)n_iters / (float)(n_iters / 16 * 16);
+        return OEM_OK;
+    }
     for (uint32_t k = 0; k < n_iters; ++k) OEM_TRY(enqueue_iteration(s, a, p));
     OEM_HIP(hipEventRecord(e1, s->stream));
     OEM_HIP(hipEventSynchronize(e1));
@@ -1327,6 +1377,33 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     *out_ms = ms;
     return OEM_OK;
     OEM_API_END("oem_time_em_iters")
+}
+
+extern "C" int oem_time_allreduce(oem_store *s, uint32_t n_calls, float *out_avg_us)
+{
+    OEM_API_BEGIN
+    if (!s || !out_avg_us || n_calls == 0) return fail(OEM_ERR_ARG, "oem_time_allreduce: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_TRY(ensure_device(s->device));
+    if (!comm_exchanges(s->comm)) return fail(OEM_ERR_STATE, "oem_time_allreduce: no communicator attached");
+    const uint32_t T = s->csr.n_txps;
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    hipEvent_t e0, e1;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream)); // untimed: first-use set-up
+    OEM_HIP(hipEventRecord(e0, s->stream));
+    for (uint32_t k = 0; k < n_calls; ++k) OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
+    OEM_HIP(hipEventRecord(e1, s->stream));
+    OEM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    OEM_TRY(comm_check(s->comm, s->stream));
+    *out_avg_us = ms * 1e3f / (float)n_calls;
+    return OEM_OK;
+    OEM_API_END("oem_time_allreduce")
 }
 
 extern "C" int oem_cells_last_timing(float *out_loop_ms, uint64_t *out_batched_passes)

@@ -1,4 +1,5 @@
-// oem_comm.cpp -- RCCL communicator over the row shards of one node.
+// oem_comm.cpp -- communicator over the row shards of one node: RCCL, and the one-shot peer-to-peer
+// exchange of oem_p2p.hip for the small (latency-bound) count vector.
 //
 // One process per GPU; each process owns one row shard of the alignment store
 // and the only exchange of the path is the sum of the n_txps partial counts
@@ -111,8 +112,26 @@ __global__ void k_local_sum(const double *const *send, int n, double *out, size_
 
 #endif // OEM_TESTING
 
+struct P2P; // oem_p2p.hip
+int p2p_create(int rank, int n_ranks, int device, P2P **out);
+void p2p_destroy(P2P *p);
+bool p2p_ready(const P2P *p);
+uint64_t p2p_capacity(const P2P *p);
+int p2p_export(P2P *p, uint64_t capacity, void *out_blob);
+int p2p_connect(P2P *p, const void *all_blobs);
+int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state);
+int p2p_reldiff(P2P *p, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st);
+int p2p_check(P2P *p, hipStream_t st);
+
+// Vectors up to this size take the peer-to-peer exchange when it is connected (latency-bound: every
+// rank reads N - 1 partials over its own links at once); larger ones (the batched bootstrap's
+// 2 * T * 4 counts) are bandwidth-bound and go to RCCL when the communicator has one.
+constexpr size_t kP2PMaxBytes = 4u << 20;
+
 struct Comm {
     ncclComm_t comm = nullptr;
+    P2P *p2p = nullptr;
+    size_t p2p_max_bytes = kP2PMaxBytes; // OEM_COMM_OPT_P2P_MAX_BYTES (0: RCCL only)
     int rank = 0;
     int n_ranks = 1;
     int device = 0;
@@ -152,12 +171,21 @@ static int local_allreduce(Comm *c, const double *send, double *recv, size_t cou
 }
 #endif // OEM_TESTING
 
-int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st)
+static bool use_p2p(const Comm *c, size_t count)
+{
+    return c && p2p_ready(c->p2p) && (!c->comm || count * sizeof(double) <= c->p2p_max_bytes);
+}
+
+// `state` (optional): the launches of a finished run skip the exchange where that costs nothing -- the
+// peer-to-peer kernels test it on the device, identically on every rank; RCCL calls are issued regardless.
+int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state)
 {
 #ifdef OEM_TESTING
     if (c && c->local) return local_allreduce(c, send, recv, count, st);
 #endif
+    if (use_p2p(c, count)) return p2p_allreduce(c->p2p, send, recv, count, st, state);
     if (!c || !c->comm) { // no exchange partner
+        if (c && c->n_ranks > 1) return fail(OEM_ERR_STATE, "communicator of %d ranks has no connected backend", c->n_ranks);
         if (send != recv)
             OEM_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, st));
         return OEM_OK;
@@ -167,12 +195,35 @@ int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t cou
     return OEM_OK;
 }
 
+// The exchange of one loop iteration fused with rel-diff / swap / clear (peer-to-peer backend only).
+bool comm_fuses_reldiff(const Comm *c, uint32_t n_txps)
+{
+#ifdef OEM_TESTING
+    if (c && c->local) return false;
+#endif
+    return use_p2p(c, n_txps) && n_txps <= p2p_capacity(c->p2p);
+}
+int comm_reldiff_fused(Comm *c, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st)
+{
+    return p2p_reldiff(c->p2p, prev, curr, state, prm, st);
+}
+// true when a launch of a finished run costs a real collective (RCCL): the host then looks at the state more often
+bool comm_exchange_is_unconditional(const Comm *c, uint32_t n_txps)
+{
+#ifdef OEM_TESTING
+    if (c && c->local) return true;
+#endif
+    return c && c->comm && !use_p2p(c, n_txps);
+}
+// after a stream synchronize: a peer-to-peer wait that timed out is reported, not hung on
+int comm_check(Comm *c, hipStream_t st) { return c && c->p2p ? p2p_check(c->p2p, st) : OEM_OK; }
+
 int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }
 #ifdef OEM_TESTING
-bool comm_exchanges(const Comm *c) { return c && (c->comm || c->local); }
+bool comm_exchanges(const Comm *c) { return c && (c->comm || c->local || p2p_ready(c->p2p)); }
 #else
-bool comm_exchanges(const Comm *c) { return c && c->comm; }
+bool comm_exchanges(const Comm *c) { return c && (c->comm || p2p_ready(c->p2p)); }
 #endif
 
 } // namespace oem
@@ -209,8 +260,9 @@ extern "C" int oem_comm_create(const void *unique_id, int rank, int n_ranks, int
     c->device = device;
     // n_ranks == 1 with a unique id still builds a real RCCL communicator (RCCL accepts one rank):
     // the single-GPU self test of the dlopen'ed entry points.  n_ranks == 1 without one is a no-op.
-    if (n_ranks > 1 || unique_id) {
-        if (!unique_id) { delete c; return fail(OEM_ERR_ARG, "oem_comm_create: unique_id is NULL"); }
+    // n_ranks > 1 without one is a communicator that will exchange peer to peer only
+    // (oem_comm_p2p_export / _connect): no RCCL is loaded.
+    if (unique_id) {
         int rc = load_rccl();
         if (rc != OEM_OK) { delete c; return rc; }
         hipError_t e = hipSetDevice(device);
@@ -252,10 +304,43 @@ extern "C" int oem_debug_local_comm_create(int n_ranks, int device, oem_comm **o
 }
 #endif // OEM_TESTING
 
+extern "C" int oem_comm_p2p_export(oem_comm *comm, uint64_t capacity, void *out_handle)
+{
+    OEM_API_BEGIN
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c || !out_handle || capacity == 0) return fail(OEM_ERR_ARG, "oem_comm_p2p_export: bad argument");
+    if (!c->p2p) OEM_TRY(p2p_create(c->rank, c->n_ranks, c->device, &c->p2p));
+    return p2p_export(c->p2p, capacity, out_handle);
+    OEM_API_END("oem_comm_p2p_export")
+}
+
+extern "C" int oem_comm_p2p_connect(oem_comm *comm, const void *all_handles)
+{
+    OEM_API_BEGIN
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c || !all_handles) return fail(OEM_ERR_ARG, "oem_comm_p2p_connect: bad argument");
+    if (!c->p2p) return fail(OEM_ERR_STATE, "oem_comm_p2p_connect: call oem_comm_p2p_export first");
+    return p2p_connect(c->p2p, all_handles);
+    OEM_API_END("oem_comm_p2p_connect")
+}
+
+extern "C" int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t value)
+{
+    OEM_API_BEGIN
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c) return fail(OEM_ERR_ARG, "oem_comm_set_option: comm is NULL");
+    switch (option) {
+    case OEM_COMM_OPT_P2P_MAX_BYTES: c->p2p_max_bytes = (size_t)value; return OEM_OK;
+    default: return fail(OEM_ERR_ARG, "oem_comm_set_option: unknown option %u", option);
+    }
+    OEM_API_END("oem_comm_set_option")
+}
+
 extern "C" void oem_comm_destroy(oem_comm *comm)
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c) return;
+    if (c->p2p) p2p_destroy(c->p2p);
     if (c->comm && g_api.CommDestroy) g_api.CommDestroy(c->comm);
     delete c;
 }

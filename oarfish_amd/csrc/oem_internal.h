@@ -114,6 +114,7 @@ struct DeviceTiled {
     uint32_t *r_slot = nullptr;
     uint16_t *q_dst = nullptr;
     uint32_t *bucket_base = nullptr;
+    uint32_t *bucket_arrived = nullptr; // n_buckets tickets of k_remote_fold_fin (zero between launches)
     std::vector<uint32_t> h_bucket_base;
     double *queue = nullptr;      // n_remote f64: increments of the remote alignments, bucket-major
     uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
@@ -224,6 +225,9 @@ int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
                          uint32_t problem_size = 0, bool skip_fold = false);
+bool can_fuse_fold_reldiff(const oem_store *s);
+int launch_em_iteration_tiled_fused(oem_store *s, double *theta, double *cnt, EmState *state, EmParams p,
+                                    const uint32_t *row_w_perm);
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
 int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
@@ -244,6 +248,11 @@ int launch_bootstrap_weights(oem_store *s, uint32_t *row_w, uint64_t n_local, ui
                              uint64_t n_global, uint64_t seed, uint32_t replica, hipStream_t stream = nullptr);
 
 // RCCL (oem_comm.cpp) ---------------------------------------------------------
-int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st);
+int comm_allreduce_sum_f64(Comm *c, const double *send, double *recv, size_t count, hipStream_t st,
+                           const EmState *state = nullptr);
+bool comm_fuses_reldiff(const Comm *c, uint32_t n_txps);
+int comm_reldiff_fused(Comm *c, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st);
+bool comm_exchange_is_unconditional(const Comm *c, uint32_t n_txps);
+int comm_check(Comm *c, hipStream_t st);
 
 } // namespace oem

@@ -1,0 +1,402 @@
+// oem_p2p.hip -- one-shot peer-to-peer all-reduce of the count vector over the row shards of one node.
+//
+// The only exchange of the EM path is the sum of the n_txps partial counts per E/M pass (SURVEY.md
+// section 8e; in the reference the shared Vec<AtomicF64> of em.rs:338-341).  At 200 k transcripts that
+// is 1.6 MB: latency-bound, and a ring (RCCL's default, 2 (N-1) steps, each bound by ONE xGMI link) is
+// the wrong shape for it.  MI355X nodes are fully connected (7 links x ~153 GB/s per GPU), so here every
+// rank publishes its partial vector in a buffer its peers have mapped (hipIpc memory handles; the same
+// address space when the ranks are threads of one process) and then reads the N - 1 remote partials
+// directly, all links in parallel, summing them in rank order:
+//
+//   k_p2p_publish   send -> own slot[parity]; system-scope fence; the last workgroup raises this
+//                   rank's flag in every peer's flag block (a peer spins on its OWN memory)
+//   k_p2p_reduce    waits for the N - 1 flags, recv[i] = sum over ranks r = 0..N-1 of slot_r[parity][i]
+//   k_p2p_reldiff   the same wait and sum fused into rel-diff / swap / clear / stopping rule
+//                   (em.rs:194-218): the reduced vector is never written and read back
+//
+// Every rank adds the partials in the same order, so the reduced vector is bit-identical on all ranks
+// and they take the identical stopping decision without a second exchange.  The slots are double-
+// buffered by the parity of a device-resident epoch counter: a rank overwrites slot[p] two exchanges
+// later, after its own previous exchange has seen every peer's flag for the exchange in between, which
+// a peer raises only after it has finished reading (stream order) -- no extra barrier.  The epoch lives
+// on the device and advances inside the kernels, so launches carry no per-call values and a chunk of
+// iterations can be replayed from a hipGraph.  Launches of a finished run (EmState::done) skip the
+// exchange on every rank alike, since the state they test is identical.
+//
+// A spinning wait is bounded (wall clock): a peer that never arrives sets an error flag that the host
+// reports as OEM_ERR_STATE instead of hanging the GPU.
+#include <unistd.h>
+
+#include <cstring>
+
+#include "oem_internal.h"
+
+namespace oem {
+
+constexpr int kP2PMaxRanks = 16;
+constexpr uint32_t kP2PMagic = 0x6f703270u; // "op2p"
+constexpr int kP2PBlock = 256;
+constexpr long long kP2PTimeoutTicks = 8ll * 100000000ll; // wall_clock64() runs at 100 MHz: 8 s
+
+// The region a rank shares with its peers (one allocation, one IPC handle).
+struct P2PShared {
+    unsigned long long flags[2][kP2PMaxRanks]; // [parity][source rank] = epoch of that rank's last publish
+    unsigned long long pad[512 - 2 * kP2PMaxRanks];
+    // double slot[2][capacity] follows
+};
+static_assert(sizeof(P2PShared) == 4096, "P2PShared header");
+
+__host__ __device__ inline double *p2p_slot(P2PShared *s, uint64_t capacity, uint32_t parity)
+{
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(s) + sizeof(P2PShared)) + (size_t)parity * capacity;
+}
+
+// rank-local control block (device memory, never shared)
+struct P2PCtl {
+    unsigned long long epoch; // completed exchanges
+    uint32_t arrived_pub;     // last-workgroup tickets
+    uint32_t arrived_red;
+    uint32_t error;           // 1: a peer's flag did not arrive in time
+    uint32_t pad[3];
+    P2PShared *peer[kP2PMaxRanks]; // mapped regions, [rank] = own
+};
+
+struct P2P {
+    int rank = 0, n_ranks = 1, device = 0;
+    uint64_t capacity = 0; // doubles per slot
+    P2PShared *self = nullptr;
+    bool self_uncached = false;
+    P2PCtl *ctl = nullptr;
+    P2PCtl *h_ctl = nullptr; // pinned copy for error checks
+    void *opened[kP2PMaxRanks] = {};  // hipIpcOpenMemHandle results to close
+    bool connected = false;
+};
+
+struct P2PBlob { // OEM_P2P_HANDLE_BYTES
+    uint32_t magic, version;
+    uint64_t pid, ptr, capacity;
+    int32_t device, rank;
+    hipIpcMemHandle_t handle;
+    char pad[OEM_P2P_HANDLE_BYTES - 4 - 4 - 8 - 8 - 8 - 4 - 4 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(P2PBlob) == OEM_P2P_HANDLE_BYTES, "P2PBlob size");
+
+namespace {
+
+__device__ __forceinline__ void sys_store_u64(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long sys_load_u64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// a peer's partial: system-scope load, so a line cached from an earlier exchange is never served
+__device__ __forceinline__ double sys_load_f64(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restrict__ send, P2PCtl *ctl,
+                                                           uint64_t capacity, uint64_t count, int rank, int n_ranks,
+                                                           const EmState *state)
+{
+    if (state && state->done) return;
+    const unsigned long long e = ctl->epoch + 1;
+    P2PShared *self = ctl->peer[rank];
+    double *slot = p2p_slot(self, capacity, (uint32_t)(e & 1));
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+        slot[i] = send[i];
+    __threadfence_system(); // this thread's part of the partial is visible to the peers
+    __syncthreads();
+    __shared__ bool is_last;
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&ctl->arrived_pub, 1u);
+        is_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
+            __threadfence_system();
+            sys_store_u64(&ctl->peer[threadIdx.x]->flags[e & 1][rank], e);
+        }
+        if (threadIdx.x == 0) ctl->arrived_pub = 0u;
+    }
+}
+
+// wait until every peer has published exchange `e` (their flags live in OUR region)
+__device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int rank, int n_ranks)
+{
+    if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
+        const unsigned long long *f = &ctl->peer[rank]->flags[e & 1][threadIdx.x];
+        const long long t0 = wall_clock64();
+        while (sys_load_u64(f) < e) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+                ctl->error = 1u;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+}
+
+__device__ __forceinline__ double p2p_sum(const P2PCtl *ctl, uint64_t capacity, uint32_t parity, uint64_t i, int rank,
+                                          int n_ranks)
+{
+    double s = 0.0;
+    for (int r = 0; r < n_ranks; ++r) { // rank order: the same sum, bit for bit, on every rank
+        const double *slot = p2p_slot(ctl->peer[r], capacity, parity);
+        s += r == rank ? slot[i] : sys_load_f64(&slot[i]);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(kP2PBlock) void k_p2p_reduce(double *__restrict__ recv, P2PCtl *ctl, uint64_t capacity,
+                                                          uint64_t count, int rank, int n_ranks, const EmState *state)
+{
+    if (state && state->done) return;
+    const unsigned long long e = ctl->epoch + 1;
+    p2p_wait(ctl, e, rank, n_ranks);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+        recv[i] = p2p_sum(ctl, capacity, (uint32_t)(e & 1), i, rank, n_ranks);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&ctl->arrived_red, 1u);
+        if (ticket == gridDim.x - 1) { // every workgroup has read `epoch` (at its start) and its share of the slots
+            ctl->arrived_red = 0u;
+            __hip_atomic_store(&ctl->epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The exchange fused into rel-diff / swap / clear / stopping rule (k_reldiff_swap_clear, oem_kernels.hip):
+// curr is this rank's partial (already published), the reduced value is summed from the slots.
+template <int kRB>
+__global__ __launch_bounds__(kRB) void k_p2p_reldiff(double *__restrict__ prev, double *__restrict__ curr, EmState *state,
+                                                      EmParams p, P2PCtl *ctl, uint64_t capacity, int rank, int n_ranks)
+{
+    if (state->done) return;
+    const unsigned long long e = ctl->epoch + 1;
+    p2p_wait(ctl, e, rank, n_ranks);
+    double rel = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps; i += gridDim.x * blockDim.x) {
+        const double cc = p2p_sum(ctl, capacity, (uint32_t)(e & 1), i, rank, n_ranks);
+        const double pc = prev[i];
+        if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
+        prev[i] = cc;                                                  // em.rs:204
+        curr[i] = 0.0;                                                 // em.rs:207
+    }
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+    __shared__ double smax[kRB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) smax[wv] = rel;
+    __syncthreads();
+    __shared__ bool is_last;
+    if (threadIdx.x == 0) {
+        double m = smax[0];
+        for (int i = 1; i < kRB / 64; ++i) m = fmax(m, smax[i]);
+        if (m > 0.0) atomicMax(&state->rel_bits, (unsigned long long)__double_as_longlong(m));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (ordering argument: k_reldiff_swap_clear)
+        const uint32_t ticket = atomicAdd(&state->blocks_arrived, 1u);
+        is_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x == 0) {
+        const unsigned long long bits = __hip_atomic_load(&state->rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double rel_diff = __longlong_as_double((long long)bits);
+        state->last_rel = rel_diff;
+        state->n_passes += 1;
+        uint32_t niter = state->niter;
+        if (rel_diff < p.conv_thresh && niter > p.min_iter_gate) { // em.rs:212 / :399
+            state->done = 1;
+            state->converged = 1;
+        } else {
+            niter += 1;                                            // em.rs:218
+            state->niter = niter;
+            if (niter >= p.max_iter) state->done = 1;              // em.rs:181
+        }
+        state->rel_bits = 0ull;
+        state->blocks_arrived = 0u;
+        __hip_atomic_store(&ctl->epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int grid_for_count(uint64_t n, int block, int max_blocks)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+} // namespace
+
+int p2p_create(int rank, int n_ranks, int device, P2P **out)
+{
+    *out = nullptr;
+    if (n_ranks > kP2PMaxRanks) return fail(OEM_ERR_ARG, "peer-to-peer exchange: at most %d ranks", kP2PMaxRanks);
+    P2P *p = new (std::nothrow) P2P();
+    if (!p) return fail(OEM_ERR_OOM, "peer-to-peer exchange: host allocation failed");
+    p->rank = rank;
+    p->n_ranks = n_ranks;
+    p->device = device;
+    *out = p;
+    return OEM_OK;
+}
+
+void p2p_destroy(P2P *p)
+{
+    if (!p) return;
+    hipSetDevice(p->device);
+    hipDeviceSynchronize();
+    for (int r = 0; r < kP2PMaxRanks; ++r)
+        if (p->opened[r]) hipIpcCloseMemHandle(p->opened[r]);
+    hipFree(p->self);
+    hipFree(p->ctl);
+    if (p->h_ctl) hipHostFree(p->h_ctl);
+    delete p;
+}
+
+bool p2p_ready(const P2P *p) { return p && p->connected; }
+uint64_t p2p_capacity(const P2P *p) { return p ? p->capacity : 0; }
+
+int p2p_export(P2P *p, uint64_t capacity, void *out_blob)
+{
+    if (!p || !out_blob || capacity == 0) return fail(OEM_ERR_ARG, "oem_comm_p2p_export: bad argument");
+    if (p->self) return fail(OEM_ERR_STATE, "oem_comm_p2p_export: already exported");
+    OEM_HIP(hipSetDevice(p->device));
+    const size_t bytes = sizeof(P2PShared) + 2 * capacity * sizeof(double);
+    // uncached (fine-grained) memory is coherent between devices without cache maintenance; where the
+    // runtime declines it for IPC, ordinary device memory with system-scope fences and loads is used
+    void *mem = nullptr;
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    bool ok = false;
+    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
+        if (p->n_ranks == 1 || hipIpcGetMemHandle(&h, mem) == hipSuccess) {
+            ok = true;
+            p->self_uncached = true;
+        } else {
+            hipFree(mem);
+            mem = nullptr;
+        }
+    }
+    (void)hipGetLastError();
+    if (!ok) {
+        OEM_HIP(hipMalloc(&mem, bytes));
+        if (p->n_ranks > 1) {
+            hipError_t e = hipIpcGetMemHandle(&h, mem);
+            if (e != hipSuccess) {
+                hipFree(mem);
+                return fail(OEM_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+            }
+        }
+    }
+    OEM_HIP(hipMemset(mem, 0, bytes));
+    p->self = static_cast<P2PShared *>(mem);
+    p->capacity = capacity;
+    OEM_HIP(hipMalloc((void **)&p->ctl, sizeof(P2PCtl)));
+    OEM_HIP(hipMemset(p->ctl, 0, sizeof(P2PCtl)));
+    OEM_HIP(hipHostMalloc((void **)&p->h_ctl, sizeof(P2PCtl), hipHostMallocDefault));
+    OEM_HIP(hipDeviceSynchronize());
+    P2PBlob b;
+    std::memset(&b, 0, sizeof(b));
+    b.magic = kP2PMagic;
+    b.version = 1;
+    b.pid = (uint64_t)getpid();
+    b.ptr = (uint64_t)(uintptr_t)mem;
+    b.capacity = capacity;
+    b.device = p->device;
+    b.rank = p->rank;
+    b.handle = h;
+    std::memcpy(out_blob, &b, sizeof(b));
+    return OEM_OK;
+}
+
+int p2p_connect(P2P *p, const void *all_blobs)
+{
+    if (!p || !all_blobs) return fail(OEM_ERR_ARG, "oem_comm_p2p_connect: bad argument");
+    if (!p->self) return fail(OEM_ERR_STATE, "oem_comm_p2p_connect: export first");
+    if (p->connected) return fail(OEM_ERR_STATE, "oem_comm_p2p_connect: already connected");
+    OEM_HIP(hipSetDevice(p->device));
+    P2PCtl h;
+    std::memset(&h, 0, sizeof(h));
+    for (int r = 0; r < p->n_ranks; ++r) {
+        P2PBlob b;
+        std::memcpy(&b, static_cast<const char *>(all_blobs) + (size_t)r * sizeof(P2PBlob), sizeof(b));
+        if (b.magic != kP2PMagic || b.version != 1 || b.rank != r)
+            return fail(OEM_ERR_ARG, "oem_comm_p2p_connect: handle %d is not rank %d's export", r, r);
+        if (b.capacity != p->capacity)
+            return fail(OEM_ERR_ARG, "oem_comm_p2p_connect: rank %d exported %llu doubles, this rank %llu", r,
+                        (unsigned long long)b.capacity, (unsigned long long)p->capacity);
+        if (r == p->rank) {
+            h.peer[r] = p->self;
+        } else if (b.pid == (uint64_t)getpid()) {
+            // a rank of this very process (ranks as threads): one address space, no handle to open
+            if (b.device != p->device) {
+                int can = 0;
+                OEM_HIP(hipDeviceCanAccessPeer(&can, p->device, b.device));
+                if (!can) return fail(OEM_ERR_STATE, "device %d cannot access device %d", p->device, b.device);
+                hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(OEM_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", b.device, hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            h.peer[r] = reinterpret_cast<P2PShared *>((uintptr_t)b.ptr);
+        } else {
+            void *m = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&m, b.handle, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess)
+                return fail(OEM_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+            p->opened[r] = m;
+            h.peer[r] = static_cast<P2PShared *>(m);
+        }
+    }
+    OEM_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    p->connected = true;
+    return OEM_OK;
+}
+
+// recv = sum over ranks of send (in place allowed); counts beyond the slot capacity go in pieces
+int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state)
+{
+    if (!p2p_ready(p)) return fail(OEM_ERR_STATE, "peer-to-peer exchange is not connected");
+    for (size_t off = 0; off < count; off += p->capacity) {
+        const uint64_t n = count - off < p->capacity ? count - off : p->capacity;
+        const int grid = grid_for_count(n, kP2PBlock, 128);
+        hipLaunchKernelGGL(k_p2p_publish, dim3(grid), dim3(kP2PBlock), 0, st, send + off, p->ctl, p->capacity, n, p->rank,
+                           p->n_ranks, state);
+        hipLaunchKernelGGL(k_p2p_reduce, dim3(grid), dim3(kP2PBlock), 0, st, recv + off, p->ctl, p->capacity, n, p->rank,
+                           p->n_ranks, state);
+    }
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+// publish this rank's partial `curr`, then rel-diff / swap / clear / stopping rule on the sum of the slots
+int p2p_reldiff(P2P *p, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st)
+{
+    if (!p2p_ready(p) || prm.n_txps > p->capacity) return fail(OEM_ERR_STATE, "peer-to-peer exchange: not connected / too small");
+    const int grid = grid_for_count(prm.n_txps, kP2PBlock, 128);
+    hipLaunchKernelGGL(k_p2p_publish, dim3(grid), dim3(kP2PBlock), 0, st, curr, p->ctl, p->capacity, (uint64_t)prm.n_txps,
+                       p->rank, p->n_ranks, state);
+    constexpr int kRB = 1024;
+    hipLaunchKernelGGL(k_p2p_reldiff<kRB>, dim3(grid_for_count(prm.n_txps, kRB, 64)), dim3(kRB), 0, st, prev, curr, state, prm,
+                       p->ctl, p->capacity, p->rank, p->n_ranks);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+// after a stream synchronize: did a wait time out?
+int p2p_check(P2P *p, hipStream_t st)
+{
+    if (!p2p_ready(p)) return OEM_OK;
+    OEM_HIP(hipMemcpyAsync(p->h_ctl, p->ctl, sizeof(P2PCtl), hipMemcpyDeviceToHost, st));
+    OEM_HIP(hipStreamSynchronize(st));
+    if (p->h_ctl->error) return fail(OEM_ERR_STATE, "peer-to-peer exchange: a rank did not arrive within 8 s (rank %d waited)", p->rank);
+    return OEM_OK;
+}
+
+} // namespace oem

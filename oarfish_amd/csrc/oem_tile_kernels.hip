@@ -355,6 +355,102 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     }
 }
 
+// k_remote_fold that also FINISHES the pass (em.rs:194-218): the workgroup that is last to flush into a
+// bucket (a ticket per bucket) owns that bucket's transcripts from then on -- every contribution to their
+// counts has been performed, the tile kernel's window flushes by stream order and the other groups' flush
+// atomics by the ticket -- and does their rel-diff / swap / clear on the spot; the workgroup that finishes
+// the last bucket applies the stopping rule.  One kernel, its launch gap and a sweep over theta / cnt from a
+// cold start less per iteration (single-GPU runs: with row shards the exchange sits between fold and rel-diff).
+// Ordering: flush atomics are device-scope read-modify-writes performed memory-side (beyond the per-XCD L2);
+// a thread drains them (vmcnt) before the workgroup's ticket, so the last ticket holder sees them all --
+// provided it reads the counts coherently (agent-scope loads: sc1, not a line of its own XCD's L2).
+__global__ __launch_bounds__(kFoldThreads) void k_remote_fold_fin(
+    const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
+    const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, double *__restrict__ theta, EmState *state,
+    EmParams p, uint32_t n_groups, uint32_t n_buckets, uint32_t *__restrict__ bucket_arrived)
+{
+    if (state->done) return;
+    __shared__ double acc[kBucket];
+    const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
+    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
+    const uint64_t span = q1 - q0;
+    const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups);
+    const uint32_t s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
+    const uint32_t base = b * kBucket;
+    if (s0 != s1) {
+        for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreads) acc[i] = 0.0;
+        __syncthreads();
+        uint32_t o = s0 + threadIdx.x;
+        for (; o + 3 * kFoldThreads < s1; o += 4 * kFoldThreads) {
+            double v[4];
+            uint32_t d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = queue[o + k * kFoldThreads];
+                d[k] = q_dst[o + k * kFoldThreads];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] != 0.0) lds_add_f64(&acc[d[k]], v[k]);
+        }
+        for (; o < s1; o += kFoldThreads) {
+            const double v = queue[o];
+            if (v != 0.0) lds_add_f64(&acc[q_dst[o]], v);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kBucket && base + i < p.n_txps; i += kFoldThreads) {
+            const double v = acc[i];
+            if (v != 0.0) unsafeAtomicAdd(&cnt[base + i], v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's flush atomics have been performed
+    __syncthreads();
+    __shared__ uint32_t last_of_bucket;
+    if (threadIdx.x == 0) last_of_bucket = atomicAdd(&bucket_arrived[b], 1u) == n_groups - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_of_bucket) return;
+
+    double rel = 0.0; // em.rs:169 / :234
+    for (uint32_t i = threadIdx.x; i < kBucket && base + i < p.n_txps; i += kFoldThreads) {
+        const uint32_t t = base + i;
+        const double cc = __hip_atomic_load(&cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double pc = theta[t];
+        if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
+        theta[t] = cc;                                                 // em.rs:204
+        cnt[t] = 0.0;                                                  // em.rs:207
+    }
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+    __shared__ double smax[kFoldThreads / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) smax[wv] = rel;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bucket_arrived[b] = 0u; // (the next launch reads it after this kernel has ended)
+        double m = smax[0];
+        for (int i = 1; i < kFoldThreads / 64; ++i) m = fmax(m, smax[i]);
+        if (m > 0.0) atomicMax(&state->rel_bits, (unsigned long long)__double_as_longlong(m));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ordering argument of k_reldiff_swap_clear)
+        const uint32_t ticket = atomicAdd(&state->blocks_arrived, 1u);
+        if (ticket == n_buckets - 1) {
+            const unsigned long long bits = __hip_atomic_load(&state->rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double rel_diff = __longlong_as_double((long long)bits);
+            state->last_rel = rel_diff;
+            state->n_passes += 1;
+            uint32_t niter = state->niter;
+            if (rel_diff < p.conv_thresh && niter > p.min_iter_gate) { // em.rs:212 / :399
+                state->done = 1;
+                state->converged = 1;
+            } else {
+                niter += 1;                                            // em.rs:218
+                state->niter = niter;
+                if (niter >= p.max_iter) state->done = 1;              // em.rs:181
+            }
+            state->rel_bits = 0ull;                                    // em.rs:234
+            state->blocks_arrived = 0u;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restrict__ row_w,
                                                        const uint32_t *__restrict__ perm,
                                                        uint32_t *__restrict__ out, uint64_t n)
@@ -386,6 +482,40 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
                            row_w_perm, problems);
 }
 
+static uint32_t fold_groups(const DeviceTiled &t)
+{
+    // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
+    // fewer, longer-running workgroups mean fewer flush atomics) ...
+    uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
+    // ... but every workgroup clears and flushes a whole 64 KiB window, which only pays for
+    // itself with >= 16 Ki queue entries to fold (1 M-read store: 32 Ki 34.5 us, 16 Ki 33.1 us, 8 Ki 35.6 us per pass)
+    const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
+    const uint32_t max_useful = (uint32_t)((per_bucket + 16383) / 16384);
+    if (n_groups > max_useful) n_groups = max_useful;
+    if (n_groups < 1) n_groups = 1;
+    return n_groups;
+}
+
+// Whether one loop iteration of this store can end in k_remote_fold_fin (fold + rel-diff + stopping rule).
+bool can_fuse_fold_reldiff(const oem_store *s)
+{
+    const DeviceTiled &t = s->tiled;
+    return t.present && t.n_tiles > 0 && t.n_remote > 0 && t.n_buckets > 0 && t.bucket_arrived != nullptr;
+}
+
+// E/M pass whose fold kernel finishes the iteration: theta <- counts, cnt <- 0, state advanced.
+int launch_em_iteration_tiled_fused(oem_store *s, double *theta, double *cnt, EmState *state, EmParams p,
+                                    const uint32_t *row_w_perm)
+{
+    OEM_TRY(launch_em_pass_tiled(s, theta, cnt, state, row_w_perm, nullptr, 0, true));
+    const DeviceTiled &t = s->tiled;
+    const uint32_t n_groups = fold_groups(t);
+    hipLaunchKernelGGL(k_remote_fold_fin, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0, s->stream, t.bucket_base,
+                       t.queue, t.q_dst, cnt, theta, state, p, n_groups, t.n_buckets, t.bucket_arrived);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold)
 {
@@ -406,15 +536,7 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     }
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
-        // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
-        // fewer, longer-running workgroups mean fewer flush atomics) ...
-        uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
-        // ... but every workgroup clears and flushes a whole 64 KiB window, which only pays for
-        // itself with >= 16 Ki queue entries to fold (1 M-read store: 32 Ki 34.5 us, 16 Ki 33.1 us, 8 Ki 35.6 us per pass)
-        const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
-        const uint32_t max_useful = (uint32_t)((per_bucket + 16383) / 16384);
-        if (n_groups > max_useful) n_groups = max_useful;
-        if (n_groups < 1) n_groups = 1;
+        const uint32_t n_groups = fold_groups(t);
         hipLaunchKernelGGL(k_remote_fold, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
                            s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
                            s->csr.n_txps, problems, problem_size);

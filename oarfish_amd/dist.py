@@ -150,6 +150,12 @@ class Comm:
 
     def __init__(self, handle):
         self.handle = handle
+        self.p2p = False        # the peer-to-peer exchange is connected on every rank
+        self.p2p_error = ""
+
+    def set_p2p_max_bytes(self, n: int):
+        """Collective: vectors above `n` bytes go to RCCL (0 = always RCCL)."""
+        _lib.check(_lib.lib().oem_comm_set_option(self.handle, _lib.OEM_COMM_OPT_P2P_MAX_BYTES, int(n)))
 
     def close(self):
         if self.handle is not None and self.handle.value:
@@ -163,22 +169,68 @@ class Comm:
             pass
 
 
-def create_comm(rank: int, world: int, device: int) -> Comm:
-    """Create the native RCCL communicator; the 128-byte unique id travels over the
-    already-initialised torch.distributed process group."""
+def _gather_bytes(raw: bytes, rank: int, world: int, device: int) -> bytes:
+    """All ranks' `raw` (equal lengths) concatenated in rank order, over the host's process group."""
+    if world == 1:
+        return raw
     import torch
     import torch.distributed as dist
+    dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return b"".join(bytes(t.cpu().tolist()) for t in parts)
+
+
+def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_capacity: int = 0) -> Comm:
+    """Create the native communicator of this rank.
+
+    ``backend``: "rccl" (the 128-byte unique id travels over the already-initialised
+    torch.distributed process group), "p2p" (no RCCL at all: the one-shot peer-to-peer exchange of
+    oem_p2p.hip -- also the only way to run several ranks on ONE device, which RCCL refuses), or
+    "both" (RCCL for large vectors, peer to peer for the count vector; ``comm.p2p`` says whether the
+    peer-to-peer side came up on every rank -- if it did not, RCCL serves everything).
+    ``p2p_capacity``: doubles per exchange buffer (n_txps, or 2 * n_txps * 4 to cover a row-sharded
+    batched bootstrap)."""
+    import torch
+    import torch.distributed as dist
+    if backend not in ("rccl", "p2p", "both"):
+        raise ValueError("backend must be 'rccl', 'p2p' or 'both'")
     L = _lib.lib()
-    buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES)()
-    if rank == 0:
-        _lib.check(L.oem_comm_unique_id(C.addressof(buf)))
-    if world > 1:
-        backend = dist.get_backend()
-        dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
-        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().tolist())
-        buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES).from_buffer_copy(raw)
+    buf = None
+    if backend != "p2p":
+        buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES)()
+        if rank == 0:
+            _lib.check(L.oem_comm_unique_id(C.addressof(buf)))
+        if world > 1:
+            bk = dist.get_backend()
+            dev = torch.device("cuda", device) if bk == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            raw = bytes(t.cpu().tolist())
+            buf = (C.c_ubyte * _lib.OEM_UNIQUE_ID_BYTES).from_buffer_copy(raw)
     h = C.c_void_p()
-    _lib.check(L.oem_comm_create(C.addressof(buf), rank, world, device, C.byref(h)))
-    return Comm(h)
+    _lib.check(L.oem_comm_create(None if buf is None else C.addressof(buf), rank, world, device, C.byref(h)))
+    comm = Comm(h)
+    comm.p2p = False
+    if backend in ("p2p", "both"):
+        if p2p_capacity <= 0:
+            raise ValueError("p2p_capacity (doubles per exchange buffer) is required for the peer-to-peer backend")
+        blob = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+        rc = L.oem_comm_p2p_export(h, int(p2p_capacity), C.addressof(blob))
+        err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
+        # every rank must take the same road: connect only if every rank exported
+        oks = _gather_bytes(bytes([1 if rc == _lib.OEM_OK else 0]), rank, world, device)
+        if all(oks):
+            blobs = _gather_bytes(bytes(blob), rank, world, device)
+            rc = L.oem_comm_p2p_connect(h, blobs)
+            err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
+            oks = _gather_bytes(bytes([1 if rc == _lib.OEM_OK else 0]), rank, world, device)
+        comm.p2p = bool(all(oks))
+        comm.p2p_error = err
+        if not comm.p2p:
+            if backend == "p2p":
+                comm.close()
+                raise _lib.OemError(_lib.OEM_ERR_STATE, "peer-to-peer exchange did not come up on every rank: " + (err or "a peer failed"))
+            _lib.check(L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_MAX_BYTES, 0))   # RCCL serves everything
+    return comm

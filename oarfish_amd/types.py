@@ -207,6 +207,12 @@ class DeviceStore:
                                                         C.byref(nbytes)))
         return float(ms.value), int(slots.value), int(nbytes.value)
 
+    def time_allreduce(self, n_calls: int) -> float:
+        """Collective: microseconds per all-reduce of the n_txps count vector (the exchange by itself)."""
+        us = C.c_float(0)
+        self._check(self._lib.oem_time_allreduce(self.handle, n_calls, C.byref(us)))
+        return float(us.value)
+
     def attach_comm(self, comm_handle, global_n_reads: int, global_row_offset: int):
         self._check(self._lib.oem_store_attach_comm(self.handle, comm_handle, global_n_reads,
                                                     global_row_offset))

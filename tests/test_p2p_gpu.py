@@ -1,0 +1,133 @@
+"""GPU tests of the peer-to-peer exchange (oem_p2p.hip): several real ranks on the ONE GPU of the box.
+
+RCCL refuses two ranks per device; hipIpc memory handles do not care, so the N > 1 path -- shards, the
+exchange of the count vector fused into the rel-diff kernel, the generic all-reduce of the m-step and of the
+row-sharded bootstrap, identical control flow on every rank -- runs here with 2-4 PROCESSES that share
+cuda:0 (tests/mp/p2p_worker.py under torch.distributed.run), and with ranks that are threads of this
+process (one address space: the peers' buffers are plain pointers)."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oarfish_amd import _lib, dist as odist, synth
+from oarfish_amd.types import DeviceStore
+from oracle import c_oracle
+from tests.common import assert_counts_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,mode", [(2, "full"), (3, "small"), (4, "full")])
+def test_row_sharded_loop_over_p2p_with_processes_sharing_one_gpu(world, mode, tmp_path):
+    out = tmp_path / "p2p.json"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "mp", "p2p_worker.py"), str(out), mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    rep = json.load(open(out))
+    assert rep["ok"] and rep["world"] == world, rep
+    print(rep)
+
+
+def _thread_ranks(world, body):
+    """`world` communicators without RCCL whose ranks are threads of this process, connected peer to peer."""
+    L = _lib.lib()
+    T_cap = body["capacity"]
+    comms = []
+    for r in range(world):
+        h = C.c_void_p()
+        _lib.check(L.oem_comm_create(None, r, world, 0, C.byref(h)))
+        comms.append(h)
+    blobs = bytearray()
+    for r in range(world):
+        b = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+        _lib.check(L.oem_comm_p2p_export(comms[r], T_cap, C.addressof(b)))
+        blobs += bytes(b)
+    for r in range(world):
+        _lib.check(L.oem_comm_p2p_connect(comms[r], bytes(blobs)))
+    res, errs = [None] * world, []
+
+    def main(rank):
+        try:
+            res[rank] = body["fn"](rank, comms[rank])
+        except Exception as e:  # pragma: no cover
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=240)
+    for h in comms:
+        L.oem_comm_destroy(h)
+    assert not errs and all(r is not None for r in res), errs
+    return res
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 5])
+def test_row_sharded_loop_over_p2p_with_ranks_as_threads(world):
+    st = synth.make_store(70_000, 5_000, seed=77)
+    T = st.n_txps
+
+    def fn(rank, comm):
+        sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, rank, world)
+        with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, T) as d:
+            d.attach_comm(comm, st.n_reads, sh.row_begin)
+            cnt, info = d.em_run(None, 400, 1e-3, 50)
+            fixed, finfo = d.em_run(None, 60, 0.0, 50)
+            boots, binfo = d.bootstrap(2, seed=5, max_iter=120)
+            return cnt, info, fixed, finfo, boots, binfo
+
+    res = _thread_ranks(world, dict(capacity=2 * T * 4, fn=fn))
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    want, wi = c_oracle.do_em(o, max_iter=400, conv_thresh=1e-3)
+    wfix, _ = c_oracle.do_em(o, max_iter=60, conv_thresh=0.0)
+    for r in range(world):
+        cnt, info, fixed, finfo, boots, binfo = res[r]
+        assert info.niter == res[0][1].niter and np.array_equal(cnt, res[0][0]) and np.array_equal(boots, res[0][4])
+        assert finfo.niter == 60 and finfo.n_passes == 61
+        assert abs(info.niter - wi.niter) <= 1
+        assert_counts_close(cnt, want, st.n_reads, T, 1e-4 if info.niter != wi.niter else 1e-9, f"rank {r}")
+        assert_counts_close(fixed, wfix, st.n_reads, T, 1e-9, f"rank {r}, 60 iterations")
+
+
+def test_p2p_argument_checks():
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.oem_comm_create(None, 0, 2, 0, C.byref(h)))
+    try:
+        b = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+        assert L.oem_comm_p2p_connect(h, C.addressof(b)) == _lib.OEM_ERR_STATE      # export first
+        assert L.oem_comm_p2p_export(h, 0, C.addressof(b)) == _lib.OEM_ERR_ARG
+        _lib.check(L.oem_comm_p2p_export(h, 1000, C.addressof(b)))
+        assert L.oem_comm_p2p_export(h, 1000, C.addressof(b)) == _lib.OEM_ERR_STATE  # once
+        junk = bytes(2 * _lib.OEM_P2P_HANDLE_BYTES)
+        assert L.oem_comm_p2p_connect(h, junk) == _lib.OEM_ERR_ARG                   # not an export
+        # a communicator of two ranks with nothing connected must not be attached (the shard would silently
+        # run as if it were the whole store)
+        st = synth.make_store(5_000, 300, seed=2)
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+            with pytest.raises(_lib.OemError) as ei:
+                d.attach_comm(h, st.n_reads, 0)
+            assert ei.value.code == _lib.OEM_ERR_STATE
+    finally:
+        L.oem_comm_destroy(h)
