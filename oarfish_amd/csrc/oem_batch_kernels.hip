@@ -95,11 +95,26 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__rest
 //   theta_l, cnt_l : [c][b]  byte (c * kEB + b) * 8 = code * kEB + b * 8   (code = 8 c, as stored)
 //   den_l          : [b][r]  remote part of the denominators, then c_ib / denom_ib
 // WT = float (as_prob alone: exact) or double (as_prob * cov_prob, the coverage model: em.rs:107-111)
-template <bool kNT, typename WT>
+// a remote record and its queue slot: see ld_remote in oem_tile_kernels.hip / oem_layout_pack.hip
+template <bool kPacked, bool kNT>
+__device__ __forceinline__ void ld_remote_b(const uint32_t *__restrict__ r_a, const uint16_t *__restrict__ r_row, uint32_t o,
+                                            uint32_t tid_base, uint32_t &t, uint32_t &row)
+{
+    if (kPacked) {
+        const uint32_t pk = ld_stream_b<kNT>(&r_a[o]);
+        t = tid_base + (pk & ((1u << kPackRowShift) - 1u));
+        row = pk >> kPackRowShift;
+    } else {
+        t = ld_stream_b<kNT>(&r_a[o]);
+        row = ld_stream_b<kNT>(&r_row[o]);
+    }
+}
+
+template <bool kNT, typename WT, bool kPacked>
 __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
-    const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
-    const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
+    const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
+    const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd, uint32_t problem_size,
     double *__restrict__ queue /* [kB][n_remote] */, uint64_t n_remote,
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
@@ -148,17 +163,22 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         load_slice_b<kNT, WT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
     uint32_t rt[kRemE], rrow[kRemE], rslot[kRemE];
     WT rw[kRemE];
+    const uint32_t tid_base = td.problem * problem_size;
+    const uint32_t *sd_t = sd + td.sd_begin - td.b_min; // slot of record i = sd_t[bucket of its transcript] + i
 #pragma unroll
     for (int k = 0; k < kRemE; ++k) {
         const uint32_t i = tx + k * kTileThreadsE;
         rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0;
         if (i < td.remote_cnt) {
             const uint32_t o = td.remote_begin + i;
-            rt[k] = ld_stream_b<kNT>(&r_tid[o]);
+            ld_remote_b<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
             rw[k] = ld_stream_b<kNT>(&r_w[o]);
-            rrow[k] = ld_stream_b<kNT>(&r_row[o]);
-            rslot[k] = ld_stream_b<kNT>(&r_slot[o]);
         }
+    }
+#pragma unroll
+    for (int k = 0; k < kRemE; ++k) {
+        const uint32_t i = tx + k * kTileThreadsE;
+        if (i < td.remote_cnt) rslot[k] = sd_t[rt[k] >> kBucketShift] + i;
     }
     // slot of this lane at step j of an epoch: (j + lane) mod kEB
     uint32_t rot8[kEB]; // byte offset of that slot inside a [c][b] window entry
@@ -182,6 +202,15 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             const uint32_t rl = (wave + kWaves * q) * 64 + lane;
             mult[q] = rl < td.n_rows ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff) : 0u;
         }
+        // multiplicities of the reads of this thread's remote records (4 KB per tile: cache-resident).  A read
+        // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote
+        // denominators are never read and its queue entries stay at the zero the slot was loaded with
+        // (launch_batch_reset_slot clears the slot's queue plane), so neither is touched.
+        uint32_t rmult[kRemE];
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k)
+            rmult[k] = tx + k * kTileThreadsE < td.remote_cnt
+                           ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rrow[k]) * kB + eoff) : 0u;
         // remote alignments: x[b] = theta[t][b] * w; the epoch's four slots are one 32-byte piece
         double rx[kRemE][kEB];
 #pragma unroll
@@ -202,19 +231,23 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // ---- remote phase A: denominators ------------------------------------------------
 #pragma unroll
         for (int k = 0; k < kRemE; ++k)
-            if (tx + k * kTileThreadsE < td.remote_cnt) {
+            if (rmult[k]) {
 #pragma unroll
-                for (int b = 0; b < kEB; ++b) lds_add(&den_l[b * kTileRows + rrow[k]], rx[k][b]);
+                for (int b = 0; b < kEB; ++b)
+                    if ((rmult[k] >> (8 * b)) & 0xffu) lds_add(&den_l[b * kTileRows + rrow[k]], rx[k][b]);
             }
         for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // overflow: park x in the queue
             const uint32_t o = td.remote_begin + i;
-            const double *tp = theta + (size_t)r_tid[o] * kB + eoff;
+            uint32_t t, row;
+            ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
+            const uint32_t q = sd_t[t >> kBucketShift] + i;
+            const double *tp = theta + (size_t)t * kB + eoff;
             const double wv = (double)r_w[o];
 #pragma unroll
             for (int b = 0; b < kEB; ++b) {
                 const double x = th(tp[b], b) * wv;
-                queue[(eoff + b) * n_remote + r_slot[o]] = x;
-                lds_add(&den_l[b * kTileRows + r_row[o]], x);
+                queue[(eoff + b) * n_remote + q] = x;
+                lds_add(&den_l[b * kTileRows + row], x);
             }
         }
         __syncthreads();
@@ -304,18 +337,22 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // ---- remote phase B: queue[slot][.] <- x_b * (c_ib / denom_ib) -------------------------
 #pragma unroll
         for (int k = 0; k < kRemE; ++k) {
-            if (tx + k * kTileThreadsE < td.remote_cnt) {
+            if (rmult[k]) {
 #pragma unroll
                 for (int b = 0; b < kEB; ++b)
-                    queue[(eoff + b) * n_remote + rslot[k]] = rx[k][b] * den_l[b * kTileRows + rrow[k]];
+                    if ((rmult[k] >> (8 * b)) & 0xffu)
+                        queue[(eoff + b) * n_remote + rslot[k]] = rx[k][b] * den_l[b * kTileRows + rrow[k]];
             }
         }
         for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
             const uint32_t o = td.remote_begin + i;
+            uint32_t t, row;
+            ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
+            const uint32_t q = sd_t[t >> kBucketShift] + i;
 #pragma unroll
             for (int b = 0; b < kEB; ++b) {
-                const size_t qi = (eoff + b) * n_remote + r_slot[o];
-                queue[qi] = queue[qi] * den_l[b * kTileRows + r_row[o]];
+                const size_t qi = (eoff + b) * n_remote + q;
+                queue[qi] = queue[qi] * den_l[b * kTileRows + row];
             }
         }
         // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b] --------------------------
@@ -501,12 +538,17 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     if (t.n_tiles == 0) return OEM_OK;
     const bool f64w = s->csr.w_is_f64;
     const uint64_t wsz = f64w ? 8 : 4;
-    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + 10);
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
+#define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK)                                                                         \
+    hipLaunchKernelGGL((k_em_tile_e<NT, WT, PK>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes, \
+                       (const WT *)W, PK ? t.r_pk : t.r_tid, (const WT *)RW, t.r_row, t.sd, t.problem_size, bb.queue,    \
+                       t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
 #define OEM_LAUNCH_TILE_E(NT, WT, W, RW)                                                                              \
-    hipLaunchKernelGGL((k_em_tile_e<NT, WT>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes,    \
-                       (const WT *)W, t.r_tid, (const WT *)RW, t.r_row, t.r_slot, bb.queue, t.n_remote, bb.theta,      \
-                       bb.cnt, bb.state, bb.row_w)
+    do {                                                                                                              \
+        if (t.packed) OEM_LAUNCH_TILE_E2(NT, WT, W, RW, true);                                                        \
+        else OEM_LAUNCH_TILE_E2(NT, WT, W, RW, false);                                                                \
+    } while (0)
     if (f64w) {
         if (nt) OEM_LAUNCH_TILE_E(true, double, t.w64, t.r_w64);
         else OEM_LAUNCH_TILE_E(false, double, t.w64, t.r_w64);
@@ -514,6 +556,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         if (nt) OEM_LAUNCH_TILE_E(true, float, t.w32, t.r_w32);
         else OEM_LAUNCH_TILE_E(false, float, t.w32, t.r_w32);
     }
+#undef OEM_LAUNCH_TILE_E2
 #undef OEM_LAUNCH_TILE_E
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
@@ -542,6 +585,8 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 
 int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot)
 {
+    // the slot's queue plane: entries of reads its new resample does not draw are never written again
+    OEM_HIP(hipMemsetAsync(bb.queue + (size_t)slot * s->tiled.n_remote, 0, sizeof(double) * (size_t)s->tiled.n_remote, bb.stream));
     const int grid = grid_for(s->csr.n_txps, 256, 256);
     hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, bb.stream, bb.theta, bb.cnt, bb.cnt2, d_init, avg,
                        s->csr.n_txps, slot);

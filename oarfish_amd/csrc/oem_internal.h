@@ -111,10 +111,14 @@ struct DeviceTiled {
     float *r_w32 = nullptr;
     double *r_w64 = nullptr;
     uint16_t *r_row = nullptr;
-    uint32_t *r_slot = nullptr;
+    uint32_t *r_slot = nullptr;   // builders' form only: replaced by the per-tile slot table `sd`
+    uint32_t *r_pk = nullptr;     // packed records (transcript - problem base | read << 22), when `packed`
+    uint32_t *sd = nullptr;       // slot table (oem_layout_pack.hip)
+    uint32_t n_sd = 0;
+    bool packed = false;
+    uint32_t problem_size = 0;    // transcripts per EM problem the records were packed against (0: one problem)
     uint16_t *q_dst = nullptr;
     uint32_t *bucket_base = nullptr;
-    uint32_t *bucket_arrived = nullptr; // n_buckets tickets of k_remote_fold_fin (zero between launches)
     std::vector<uint32_t> h_bucket_base;
     double *queue = nullptr;      // n_remote f64: increments of the remote alignments, bucket-major
     uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
@@ -222,12 +226,12 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 // row_w is in the caller's read order; it is permuted into tile order first.
 // oem_layout_device.hip: the tiled layout built on the device from the resident CSR
 int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built);
+// oem_layout_pack.hip: slot table + packed remote records, after either builder
+int pack_remote_records(oem_store *s, uint32_t problem_size, bool keep_unpacked);
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
                          uint32_t problem_size = 0, bool skip_fold = false);
-bool can_fuse_fold_reldiff(const oem_store *s);
-int launch_em_iteration_tiled_fused(oem_store *s, double *theta, double *cnt, EmState *state, EmParams p,
-                                    const uint32_t *row_w_perm);
+
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
 int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);

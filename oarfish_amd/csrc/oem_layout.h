@@ -42,6 +42,10 @@ constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB 
 constexpr uint32_t kWinWide = 2048;   // window cap of sparse stores (few reads per transcript: per-cell batches)
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
 constexpr uint32_t kBucket = 8192;    // transcripts per remote bucket (64 KiB of LDS)
+constexpr uint32_t kBucketShift = 13;
+static_assert((1u << kBucketShift) == kBucket, "bucket of a transcript = id >> kBucketShift");
+constexpr uint32_t kPackRowShift = 22; // packed remote record: (transcript - problem base) | read-in-tile << 22
+static_assert((kTileRows - 1) >> (32 - kPackRowShift) == 0, "the read index must fit above the transcript bits");
 
 constexpr uint32_t kTileSlices = kTileRows / 64;
 
@@ -60,7 +64,9 @@ struct TileDesc { // 64 bytes
     uint8_t width[kTileSlices]; // max local alignments of the 64 reads of each slice (0 = no slice)
     uint32_t n_slices;
     uint32_t problem;      // independent EM problem the tile belongs to (per-cell batches); 0 otherwise
-    uint32_t pad[2];
+    // filled by pack_remote_records (oem_layout_pack.hip), zero as the builders leave the descriptor:
+    uint32_t sd_begin;     // the tile's slot table: sd[sd_begin + bucket - b_min] + (record index in the tile) = queue slot
+    uint32_t b_min;        // bucket of the tile's first remote record
 };
 static_assert(sizeof(TileDesc) == 64, "TileDesc layout");
 static_assert(kTileSlices == 16, "TileDesc::width is sized for 16 slices");

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restr
 // wait until every peer has published exchange `e` (their flags live in OUR region)
 __device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int rank, int n_ranks)
 {
-    if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
+    // (once a wait has timed out the run is lost: later launches do not wait another 8 s each)
+    if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank &&
+        !__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         const unsigned long long *f = &ctl->peer[rank]->flags[e & 1][threadIdx.x];
         const long long t0 = wall_clock64();
         while (sys_load_u64(f) < e) {

@@ -45,6 +45,8 @@ extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out
     OEM_TRY(hash_dev(t.perm, 4 * t.n_rows, &out[5]));
     OEM_TRY(hash_dev(t.codes, 4 * (c_slots + 1) * 64, &out[6]));
     OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.w64 : (const void *)t.w32, wsz * (w_slots + 1) * 64, &out[7]));
+    if (!t.r_tid || !t.r_row || !t.r_slot)
+        return fail(OEM_ERR_STATE, "oem_debug_layout_hash: the builders' remote streams were dropped (set OEM_KEEP_UNPACKED=1)");
     OEM_TRY(hash_dev(t.r_tid, 4 * t.n_remote, &out[8]));
     OEM_TRY(hash_dev(s->csr.w_is_f64 ? (const void *)t.r_w64 : (const void *)t.r_w32, wsz * t.n_remote, &out[9]));
     OEM_TRY(hash_dev(t.r_row, 2 * t.n_remote, &out[10]));
@@ -52,6 +54,12 @@ extern "C" int oem_debug_layout_hash(oem_store *s, uint64_t *out, uint32_t n_out
     OEM_TRY(hash_dev(t.q_dst, 2 * t.n_remote, &out[12]));
     OEM_TRY(hash_dev(t.bucket_base, 4 * ((size_t)t.n_buckets + 1), &out[13]));
     if (n_out > 14) out[14] = t.built_on_device ? 1 : 0;
+    if (n_out > 17) { // the slim form the kernels read (oem_layout_pack.hip)
+        OEM_TRY(hash_dev(t.sd, 4 * (size_t)t.n_sd, &out[15]));
+        out[16] = 0;
+        if (t.packed) OEM_TRY(hash_dev(t.r_pk, 4 * t.n_remote, &out[16]));
+        out[17] = t.packed ? 1 : 0;
+    }
     return OEM_OK;
     OEM_API_END("oem_debug_layout_hash")
 }

@@ -91,7 +91,10 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
     }
 }
 
-template <typename WT, int kCh, int kCopies>
+// kPlane = 0: the kCopies count-window copies are interleaved (entry c of copy p at (c * kCopies + p) * 8);
+// kPlane > 0: they are planes of kPlane entries (entry c of copy p at (p * kPlane + c) * 8), kPlane odd, so
+// that the copies of one entry AND neighbouring entries of one copy fall on different LDS banks.
+template <typename WT, int kCh, int kCopies, uint32_t kPlane>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
@@ -134,7 +137,8 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     // (c * kCopies + p) * 8): lanes of different copies that add into the same
     // transcript hit different addresses (and adjacent banks), which divides the
     // same-address serialisation of the LDS atomics by up to kCopies.
-    const uint32_t copy_off = (lane % kCopies) * 8u;
+    constexpr uint32_t kMul = kPlane ? 1u : (uint32_t)kCopies;                  // byte offset of entry c: 8 c * kMul
+    const uint32_t copy_off = (lane % kCopies) * (kPlane ? kPlane * 8u : 8u);
     // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
     // share it, and 64 same-address LDS atomics would serialise: reduce across the
     // wavefront and let one lane add.
@@ -144,9 +148,9 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
             const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kMul), sum);
         } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
+            lds_add_f64(lds_at(cnt_l, off0 * kMul + copy_off), v0);          // em.rs:128-129
         }
     }
 #pragma unroll
@@ -154,30 +158,48 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
             const double v = x[k] * inv;
-            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kMul + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
         const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
-        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kMul + copy_off), v);
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT = kWin>
+// A remote record (oem_layout_pack.hip): kPacked: one u32 = (transcript - problem base) | read << 22;
+// otherwise transcript u32 + read u16.  Its queue slot comes from the tile's slot table.
+template <bool kPacked, bool kNT>
+__device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, const uint16_t *__restrict__ r_row, uint32_t o,
+                                          uint32_t tid_base, uint32_t &t, uint32_t &row)
+{
+    if (kPacked) {
+        const uint32_t pk = ld_stream<kNT>(&r_a[o]);
+        t = tid_base + (pk & ((1u << kPackRowShift) - 1u));
+        row = pk >> kPackRowShift;
+    } else {
+        t = ld_stream<kNT>(&r_a[o]);
+        row = ld_stream<kNT>(&r_row[o]);
+    }
+}
+
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked,
+          bool kPlanar = false>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
-    const WT *__restrict__ w, const uint32_t *__restrict__ r_tid, const WT *__restrict__ r_w,
-    const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ r_slot,
+    const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
+    const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
-    const BatchState *__restrict__ problems)
+    const BatchState *__restrict__ problems, uint32_t problem_size)
 {
     if (state && state->done) return;
 
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
-    __shared__ double cnt_l[kWinT * kCopies];
+    constexpr uint32_t kPlane = (kPlanar && kCopies > 1) ? kWinT + 1 : 0u; // entries per count-window plane (odd)
+    __shared__ double cnt_l[kPlane ? kPlane * kCopies : kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
@@ -215,31 +237,37 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
     uint32_t rslot[kRem]; // their slot in the bucket-major queue
+    const uint32_t tid_base = td.problem * problem_size; // first transcript of the tile's EM problem (0: one problem)
+    const uint32_t *sd_t = sd + td.sd_begin - td.b_min;  // slot of record i = sd_t[bucket of its transcript] + i
     {
         uint32_t rt[kRem];
         WT rw[kRem];
         if (td.remote_cnt) { // wave-uniform
             // branch-free: out-of-range slots re-read the tile's last record and carry no weight,
-            // so the 4 x kRem loads issue back to back
+            // so the loads issue back to back
             const uint32_t last = td.remote_cnt - 1;
 #pragma unroll
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-                rt[k] = ld_stream<kNT>(&r_tid[o]);
+                ld_remote<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
                 rw[k] = ld_stream<kNT>(&r_w[o]);
-                rrow[k] = ld_stream<kNT>(&r_row[o]);
-                rslot[k] = ld_stream<kNT>(&r_slot[o]);
             }
 #pragma unroll
             for (int k = 0; k < kRem; ++k)
                 if (tx + k * kTileThreads >= td.remote_cnt) rw[k] = (WT)0;
         } else {
 #pragma unroll
-            for (int k = 0; k < kRem; ++k) { rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0; }
+            for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
         }
 #pragma unroll
         for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
+        // the slots are wanted last (phase B): a few words per tile, cache-resident, off the critical path
+#pragma unroll
+        for (int k = 0; k < kRem; ++k) {
+            const uint32_t i = tx + k * kTileThreads;
+            rslot[k] = td.remote_cnt ? sd_t[rt[k] >> kBucketShift] + (i < td.remote_cnt ? i : td.remote_cnt - 1) : 0u;
+        }
     }
     {
         constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
@@ -255,7 +283,14 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             if (i < td.win_len) theta_l[i] = tw[u];
         }
     }
-    for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
+    if (kPlane) {
+        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
+#pragma unroll
+            for (int p = 0; p < kCopies; ++p) cnt_l[p * kPlane + i] = 0.0;
+        }
+    } else {
+        for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
+    }
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     __syncthreads();
 
@@ -265,9 +300,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         if (tx + k * kTileThreads < td.remote_cnt) lds_add_f64(&den_l[rrow[k]], rx[k]);
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) { // overflow: park in the queue
         const uint32_t o = td.remote_begin + i;
-        const double x = theta[r_tid[o]] * (double)r_w[o];
-        queue[r_slot[o]] = x;
-        lds_add_f64(&den_l[r_row[o]], x);
+        uint32_t t, row;
+        ld_remote<kPacked, false>(r_a, r_row, o, tid_base, t, row);
+        const double x = theta[t] * (double)r_w[o];
+        queue[sd_t[t >> kBucketShift] + i] = x;
+        lds_add_f64(&den_l[row], x);
     }
     __syncthreads();
 
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             load_slice<WT, kCh, kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+            fold_slice<WT, kCh, kCopies, kPlane>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
                        theta_l, cnt_l, den_l, row_w_perm);
     }
     __syncthreads();
@@ -292,15 +329,17 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
-        const uint32_t q = r_slot[o];
-        queue[q] = queue[q] * den_l[r_row[o]];
+        uint32_t t, row;
+        ld_remote<kPacked, false>(r_a, r_row, o, tid_base, t, row);
+        const uint32_t q = sd_t[t >> kBucketShift] + i;
+        queue[q] = queue[q] * den_l[row];
     }
 
     // ---- flush the window: consecutive lanes -> consecutive addresses ---------------
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         double v = 0.0;
 #pragma unroll
-        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
+        for (int p = 0; p < kCopies; ++p) v += kPlane ? cnt_l[p * kPlane + i] : cnt_l[i * kCopies + p];
         if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
 }
@@ -355,102 +394,6 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     }
 }
 
-// k_remote_fold that also FINISHES the pass (em.rs:194-218): the workgroup that is last to flush into a
-// bucket (a ticket per bucket) owns that bucket's transcripts from then on -- every contribution to their
-// counts has been performed, the tile kernel's window flushes by stream order and the other groups' flush
-// atomics by the ticket -- and does their rel-diff / swap / clear on the spot; the workgroup that finishes
-// the last bucket applies the stopping rule.  One kernel, its launch gap and a sweep over theta / cnt from a
-// cold start less per iteration (single-GPU runs: with row shards the exchange sits between fold and rel-diff).
-// Ordering: flush atomics are device-scope read-modify-writes performed memory-side (beyond the per-XCD L2);
-// a thread drains them (vmcnt) before the workgroup's ticket, so the last ticket holder sees them all --
-// provided it reads the counts coherently (agent-scope loads: sc1, not a line of its own XCD's L2).
-__global__ __launch_bounds__(kFoldThreads) void k_remote_fold_fin(
-    const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
-    const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, double *__restrict__ theta, EmState *state,
-    EmParams p, uint32_t n_groups, uint32_t n_buckets, uint32_t *__restrict__ bucket_arrived)
-{
-    if (state->done) return;
-    __shared__ double acc[kBucket];
-    const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
-    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
-    const uint64_t span = q1 - q0;
-    const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups);
-    const uint32_t s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
-    const uint32_t base = b * kBucket;
-    if (s0 != s1) {
-        for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreads) acc[i] = 0.0;
-        __syncthreads();
-        uint32_t o = s0 + threadIdx.x;
-        for (; o + 3 * kFoldThreads < s1; o += 4 * kFoldThreads) {
-            double v[4];
-            uint32_t d[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = queue[o + k * kFoldThreads];
-                d[k] = q_dst[o + k * kFoldThreads];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (v[k] != 0.0) lds_add_f64(&acc[d[k]], v[k]);
-        }
-        for (; o < s1; o += kFoldThreads) {
-            const double v = queue[o];
-            if (v != 0.0) lds_add_f64(&acc[q_dst[o]], v);
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < kBucket && base + i < p.n_txps; i += kFoldThreads) {
-            const double v = acc[i];
-            if (v != 0.0) unsafeAtomicAdd(&cnt[base + i], v);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's flush atomics have been performed
-    __syncthreads();
-    __shared__ uint32_t last_of_bucket;
-    if (threadIdx.x == 0) last_of_bucket = atomicAdd(&bucket_arrived[b], 1u) == n_groups - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!last_of_bucket) return;
-
-    double rel = 0.0; // em.rs:169 / :234
-    for (uint32_t i = threadIdx.x; i < kBucket && base + i < p.n_txps; i += kFoldThreads) {
-        const uint32_t t = base + i;
-        const double cc = __hip_atomic_load(&cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double pc = theta[t];
-        if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
-        theta[t] = cc;                                                 // em.rs:204
-        cnt[t] = 0.0;                                                  // em.rs:207
-    }
-    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
-    __shared__ double smax[kFoldThreads / 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) smax[wv] = rel;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bucket_arrived[b] = 0u; // (the next launch reads it after this kernel has ended)
-        double m = smax[0];
-        for (int i = 1; i < kFoldThreads / 64; ++i) m = fmax(m, smax[i]);
-        if (m > 0.0) atomicMax(&state->rel_bits, (unsigned long long)__double_as_longlong(m));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ordering argument of k_reldiff_swap_clear)
-        const uint32_t ticket = atomicAdd(&state->blocks_arrived, 1u);
-        if (ticket == n_buckets - 1) {
-            const unsigned long long bits = __hip_atomic_load(&state->rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double rel_diff = __longlong_as_double((long long)bits);
-            state->last_rel = rel_diff;
-            state->n_passes += 1;
-            uint32_t niter = state->niter;
-            if (rel_diff < p.conv_thresh && niter > p.min_iter_gate) { // em.rs:212 / :399
-                state->done = 1;
-                state->converged = 1;
-            } else {
-                niter += 1;                                            // em.rs:218
-                state->niter = niter;
-                if (niter >= p.max_iter) state->done = 1;              // em.rs:181
-            }
-            state->rel_bits = 0ull;                                    // em.rs:234
-            state->blocks_arrived = 0u;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restrict__ row_w,
                                                        const uint32_t *__restrict__ perm,
                                                        uint32_t *__restrict__ out, uint64_t n)
@@ -467,19 +410,24 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 // remote alignments per thread in registers; 4 interleaved count-window copies for the narrow
 // window cap, one for the wide cap of sparse stores (40 KiB LDS; same-address atomics are rare
 // when few reads share a transcript).
-template <typename WT, bool kNT>
+template <typename WT, bool kNT, bool kPacked>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
                         const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
 {
     const DeviceTiled &t = s->tiled;
+    const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide>), dim3(t.n_tiles), dim3(256), 0, s->stream,
-                           t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, theta, cnt, state,
-                           row_w_perm, problems);
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+                           t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
+                           row_w_perm, problems, t.problem_size);
+    else if (knob("OEM_TILE_PLANAR", 1) != 0)
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, true>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+                           t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
+                           row_w_perm, problems, t.problem_size);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin>), dim3(t.n_tiles), dim3(256), 0, s->stream,
-                           t.tiles, t.codes, w, t.r_tid, r_w, t.r_row, t.r_slot, t.queue, theta, cnt, state,
-                           row_w_perm, problems);
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+                           t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
+                           row_w_perm, problems, t.problem_size);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)
@@ -496,26 +444,6 @@ static uint32_t fold_groups(const DeviceTiled &t)
     return n_groups;
 }
 
-// Whether one loop iteration of this store can end in k_remote_fold_fin (fold + rel-diff + stopping rule).
-bool can_fuse_fold_reldiff(const oem_store *s)
-{
-    const DeviceTiled &t = s->tiled;
-    return t.present && t.n_tiles > 0 && t.n_remote > 0 && t.n_buckets > 0 && t.bucket_arrived != nullptr;
-}
-
-// E/M pass whose fold kernel finishes the iteration: theta <- counts, cnt <- 0, state advanced.
-int launch_em_iteration_tiled_fused(oem_store *s, double *theta, double *cnt, EmState *state, EmParams p,
-                                    const uint32_t *row_w_perm)
-{
-    OEM_TRY(launch_em_pass_tiled(s, theta, cnt, state, row_w_perm, nullptr, 0, true));
-    const DeviceTiled &t = s->tiled;
-    const uint32_t n_groups = fold_groups(t);
-    hipLaunchKernelGGL(k_remote_fold_fin, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0, s->stream, t.bucket_base,
-                       t.queue, t.q_dst, cnt, theta, state, p, n_groups, t.n_buckets, t.bucket_arrived);
-    OEM_HIP(hipGetLastError());
-    return OEM_OK;
-}
-
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold)
 {
@@ -524,16 +452,22 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     const bool f64w = s->csr.w_is_f64;
     // matrix bytes one pass streams; beyond the Infinity Cache they are loaded non-temporally
     const uint64_t wsz = f64w ? 8 : 4;
-    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + 10);
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
     const long nt_knob = knob("OEM_TILE_NT", -1); // testing build: 0 never, 1 always
     const bool nt = nt_knob < 0 ? stream_bytes > (192ull << 20) : nt_knob != 0;
+#define OEM_TILE(WT, NT, W, RW)                                                                             \
+    do {                                                                                                   \
+        if (t.packed) launch_tile<WT, NT, true>(s, W, RW, theta, cnt, state, row_w_perm, problems);                \
+        else launch_tile<WT, NT, false>(s, W, RW, theta, cnt, state, row_w_perm, problems);                        \
+    } while (0)
     if (f64w) {
-        if (nt) launch_tile<double, true>(s, t.w64, t.r_w64, theta, cnt, state, row_w_perm, problems);
-        else launch_tile<double, false>(s, t.w64, t.r_w64, theta, cnt, state, row_w_perm, problems);
+        if (nt) OEM_TILE(double, true, t.w64, t.r_w64);
+        else OEM_TILE(double, false, t.w64, t.r_w64);
     } else {
-        if (nt) launch_tile<float, true>(s, t.w32, t.r_w32, theta, cnt, state, row_w_perm, problems);
-        else launch_tile<float, false>(s, t.w32, t.r_w32, theta, cnt, state, row_w_perm, problems);
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32);
+        else OEM_TILE(float, false, t.w32, t.r_w32);
     }
+#undef OEM_TILE
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
         const uint32_t n_groups = fold_groups(t);

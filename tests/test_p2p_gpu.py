@@ -83,8 +83,11 @@ def _thread_ranks(world, body):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_loop_over_p2p_with_ranks_as_threads(world):
+    """(At most as many ranks on one device as the runtime has hardware queues, four by default: the waiting
+    kernel of one rank and the publishing kernel of another must not share a queue.  One rank per GPU, the
+    production arrangement, has no such limit.)"""
     st = synth.make_store(70_000, 5_000, seed=77)
     T = st.n_txps
 
