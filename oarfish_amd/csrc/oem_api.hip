@@ -196,12 +196,13 @@ int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
     return OEM_OK;
 }
 
-// A chunk of the loop as a hipGraph.  Replaying kGraphIters iterations from an instantiated graph instead of
-// launching their kernels one by one is worth 10-12 % of the iteration at every size measured (10 M reads:
-// 0.233 -> 0.205 ms; 1 M reads: 37.8 -> 33.9 us, profiles/r03_notes.md): what a kernel boundary costs on a
-// stream -- the dispatch, the barrier and the cache maintenance between two dependent launches -- is paid
-// per graph launch, not per kernel.  Nothing in an iteration carries a per-launch value (loop state, stopping
-// rule and the peer-to-peer epoch live on the device), so one captured chunk serves the whole run.
+// A chunk of the loop as a hipGraph -- an experiment that stays reachable (OEM_GRAPH=1 in the test-only
+// library), not the product path: replaying 16 iterations from an instantiated graph instead of launching
+// their kernels one by one changes nothing measurable on MI355X (10 M reads: 0.2240 vs 0.2239 ms per
+// iteration; 1 M reads: 38.1 vs 38.1-38.8 us, profiles/r03_notes.md) -- dependent launches on one stream
+// already follow each other within ~1 us, and the host is far ahead of the device.  Nothing in an
+// iteration carries a per-launch value (loop state, stopping rule and the peer-to-peer epoch live on the
+// device), so one captured chunk serves a whole run.
 constexpr uint32_t kGraphIters = 16;
 
 struct ChunkGraph {
@@ -248,10 +249,10 @@ int capture_chunk(hipStream_t st, uint32_t n, F &&body, ChunkGraph *out)
 }
 
 // RCCL calls are not captured (a row shard that exchanges through RCCL launches directly); the
-// peer-to-peer exchange is plain kernels.  OEM_GRAPH=0 (test-only library): direct launches, for A/B.
+// peer-to-peer exchange is plain kernels.
 bool graph_ok(const oem_store *s, size_t exchange_count = 0)
 {
-    return knob("OEM_GRAPH", 1) != 0 &&
+    return knob("OEM_GRAPH", 0) != 0 &&
            !comm_exchange_is_unconditional(s->comm, exchange_count ? exchange_count : s->csr.n_txps);
 }
 

@@ -65,7 +65,6 @@ struct P2P {
     int rank = 0, n_ranks = 1, device = 0;
     uint64_t capacity = 0; // doubles per slot
     P2PShared *self = nullptr;
-    bool self_uncached = false;
     P2PCtl *ctl = nullptr;
     P2PCtl *h_ctl = nullptr; // pinned copy for error checks
     void *opened[kP2PMaxRanks] = {};  // hipIpcOpenMemHandle results to close
@@ -270,30 +269,19 @@ int p2p_export(P2P *p, uint64_t capacity, void *out_blob)
     if (p->self) return fail(OEM_ERR_STATE, "oem_comm_p2p_export: already exported");
     OEM_HIP(hipSetDevice(p->device));
     const size_t bytes = sizeof(P2PShared) + 2 * capacity * sizeof(double);
-    // uncached (fine-grained) memory is coherent between devices without cache maintenance; where the
-    // runtime declines it for IPC, ordinary device memory with system-scope fences and loads is used
+    // Ordinary (cached) device memory: coherence with the peers comes from the system-scope fence before a
+    // flag is raised, the system-scope acquire of the flags and system-scope loads of the peers' partials.
+    // (Uncached memory was tried first: every access then goes to memory one lane at a time -- a 200 k-entry
+    // exchange of ONE rank with itself took 25 us, profiles/r03_notes.md.)
     void *mem = nullptr;
     hipIpcMemHandle_t h;
     std::memset(&h, 0, sizeof(h));
-    bool ok = false;
-    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
-        if (p->n_ranks == 1 || hipIpcGetMemHandle(&h, mem) == hipSuccess) {
-            ok = true;
-            p->self_uncached = true;
-        } else {
+    OEM_HIP(hipMalloc(&mem, bytes));
+    if (p->n_ranks > 1) {
+        hipError_t e = hipIpcGetMemHandle(&h, mem);
+        if (e != hipSuccess) {
             hipFree(mem);
-            mem = nullptr;
-        }
-    }
-    (void)hipGetLastError();
-    if (!ok) {
-        OEM_HIP(hipMalloc(&mem, bytes));
-        if (p->n_ranks > 1) {
-            hipError_t e = hipIpcGetMemHandle(&h, mem);
-            if (e != hipSuccess) {
-                hipFree(mem);
-                return fail(OEM_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
-            }
+            return fail(OEM_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
         }
     }
     OEM_HIP(hipMemset(mem, 0, bytes));

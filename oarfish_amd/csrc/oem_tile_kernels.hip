@@ -91,10 +91,7 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
     }
 }
 
-// kPlane = 0: the kCopies count-window copies are interleaved (entry c of copy p at (c * kCopies + p) * 8);
-// kPlane > 0: they are planes of kPlane entries (entry c of copy p at (p * kPlane + c) * 8), kPlane odd, so
-// that the copies of one entry AND neighbouring entries of one copy fall on different LDS banks.
-template <typename WT, int kCh, int kCopies, uint32_t kPlane>
+template <typename WT, int kCh, int kCopies>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
@@ -137,8 +134,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     // (c * kCopies + p) * 8): lanes of different copies that add into the same
     // transcript hit different addresses (and adjacent banks), which divides the
     // same-address serialisation of the LDS atomics by up to kCopies.
-    constexpr uint32_t kMul = kPlane ? 1u : (uint32_t)kCopies;                  // byte offset of entry c: 8 c * kMul
-    const uint32_t copy_off = (lane % kCopies) * (kPlane ? kPlane * 8u : 8u);
+    const uint32_t copy_off = (lane % kCopies) * 8u;
     // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
     // share it, and 64 same-address LDS atomics would serialise: reduce across the
     // wavefront and let one lane add.
@@ -148,9 +144,9 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
             const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kMul), sum);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
         } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, off0 * kMul + copy_off), v0);          // em.rs:128-129
+            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
         }
     }
 #pragma unroll
@@ -158,14 +154,14 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
             const double v = x[k] * inv;
-            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kMul + copy_off), v);
+            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
         const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
-        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kMul + copy_off), v);
+        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
@@ -185,8 +181,7 @@ __device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, cons
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked,
-          bool kPlanar = false>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
@@ -198,8 +193,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     if (state && state->done) return;
 
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
-    constexpr uint32_t kPlane = (kPlanar && kCopies > 1) ? kWinT + 1 : 0u; // entries per count-window plane (odd)
-    __shared__ double cnt_l[kPlane ? kPlane * kCopies : kWinT * kCopies];
+    __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
@@ -283,14 +277,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             if (i < td.win_len) theta_l[i] = tw[u];
         }
     }
-    if (kPlane) {
-        for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
-#pragma unroll
-            for (int p = 0; p < kCopies; ++p) cnt_l[p * kPlane + i] = 0.0;
-        }
-    } else {
-        for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
-    }
+    for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     __syncthreads();
 
@@ -316,7 +303,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             load_slice<WT, kCh, kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies, kPlane>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+            fold_slice<WT, kCh, kCopies>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
                        theta_l, cnt_l, den_l, row_w_perm);
     }
     __syncthreads();
@@ -339,7 +326,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         double v = 0.0;
 #pragma unroll
-        for (int p = 0; p < kCopies; ++p) v += kPlane ? cnt_l[p * kPlane + i] : cnt_l[i * kCopies + p];
+        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
         if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
 }
@@ -418,10 +405,6 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
     if (t.win_cap > kWin)
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
-                           t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size);
-    else if (knob("OEM_TILE_PLANAR", 1) != 0)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, true>), dim3(t.n_tiles), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size);
     else

@@ -44,6 +44,7 @@ try:
             res["boots"], bi = d.bootstrap(3, seed=17, max_iter=200)
             res["niter"] = [i1.niter, i2.niter] + [b.niter for b in bi]
             res["allreduce_us"] = d.time_allreduce(50)
+            res["iteration_us"] = d.time_em_iters(200) / 200 * 1e3   # tile + fold + publish + exchange-in-rel-diff
         finally:
             comm.close()
 except Exception as e:   # every rank must reach the gather
@@ -82,7 +83,11 @@ if rank == 0:
                 assert abs(n[2 + b] - wbi.niter) <= 1
                 assert_counts_close(rs[0]["boots"][b], wb, st.n_reads, T, 1e-4 if n[2 + b] != wbi.niter else 1e-9,
                                     f"bootstrap {b}")
-            report = {"world": world, "niter": n, "allreduce_us": [r_["allreduce_us"] for r_ in rs]}
+            with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as full:
+                full.time_em_iters(50)
+                one = full.time_em_iters(200) / 200 * 1e3
+            report = {"world": world, "niter": n, "n_txps": T, "allreduce_us": [r_["allreduce_us"] for r_ in rs],
+                      "sharded_iteration_us": [r_["iteration_us"] for r_ in rs], "unsharded_iteration_us": one}
         except AssertionError as e:
             ok, report = False, {"assertion": repr(e)[:2000]}
     json.dump({"ok": ok, **report}, open(out_path, "w"))
