@@ -82,19 +82,31 @@ static_assert(sizeof(P2PBlob) == OEM_P2P_HANDLE_BYTES, "P2PBlob size");
 
 namespace {
 
+// Coherence by construction, without cache-wide maintenance.  Every access to a shared region -- partials
+// and flags, own and peers' -- is a system-scope access (sc0 sc1: stores write through to memory, loads are
+// served by memory), so nothing shared ever sits dirty or stale in a per-XCD L2; ordering is by waiting for
+// the stores to be acknowledged (vmcnt) before a workgroup takes its ticket, and the flags go up after the
+// last ticket.  The generic __threadfence_system() would do the same job with an L2 write-back AND an L2
+// invalidate per wavefront (buffer_wbl2 + buffer_inv): measured, a 200 k-entry exchange of one rank with
+// itself took 25 us that way (profiles/r03_notes.md).
 __device__ __forceinline__ void sys_store_u64(unsigned long long *p, unsigned long long v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ unsigned long long sys_load_u64(const unsigned long long *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// a peer's partial: system-scope load, so a line cached from an earlier exchange is never served
+__device__ __forceinline__ void sys_store_f64(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ double sys_load_f64(const double *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// every store this thread has issued is acknowledged by memory
+__device__ __forceinline__ void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restrict__ send, P2PCtl *ctl,
                                                            uint64_t capacity, uint64_t count, int rank, int n_ranks,
@@ -105,8 +117,8 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restr
     P2PShared *self = ctl->peer[rank];
     double *slot = p2p_slot(self, capacity, (uint32_t)(e & 1));
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
-        slot[i] = send[i];
-    __threadfence_system(); // this thread's part of the partial is visible to the peers
+        sys_store_f64(&slot[i], send[i]);
+    stores_performed(); // this thread's part of the partial is in memory
     __syncthreads();
     __shared__ bool is_last;
     if (threadIdx.x == 0) {
@@ -114,11 +126,9 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restr
         is_last = ticket == gridDim.x - 1;
     }
     __syncthreads();
-    if (is_last) {
-        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
-            __threadfence_system();
+    if (is_last) { // every workgroup's part is in memory: raise this rank's flag at every peer
+        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank)
             sys_store_u64(&ctl->peer[threadIdx.x]->flags[e & 1][rank], e);
-        }
         if (threadIdx.x == 0) ctl->arrived_pub = 0u;
     }
 }
@@ -140,7 +150,6 @@ __device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int 
         }
     }
     __syncthreads();
-    __threadfence_system();
 }
 
 __device__ __forceinline__ double p2p_sum(const P2PCtl *ctl, uint64_t capacity, uint32_t parity, uint64_t i, int rank,
@@ -149,7 +158,7 @@ __device__ __forceinline__ double p2p_sum(const P2PCtl *ctl, uint64_t capacity, 
     double s = 0.0;
     for (int r = 0; r < n_ranks; ++r) { // rank order: the same sum, bit for bit, on every rank
         const double *slot = p2p_slot(ctl->peer[r], capacity, parity);
-        s += r == rank ? slot[i] : sys_load_f64(&slot[i]);
+        s += sys_load_f64(&slot[i]); // (own slot too: it was written through, a cached copy may predate that)
     }
     return s;
 }
