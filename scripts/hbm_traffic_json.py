@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Turn the separate FETCH_SIZE / WRITE_SIZE / calibration passes of scripts/collect_profiles.sh
 into profiles/<tag>_<wl>_hbm_traffic.json (HBM bytes per launch, per kernel; the file bench.py's
-roofline.traffic is read from).  usage: hbm_traffic_json.py <collect dir> <workload> <out.json>"""
+roofline.traffic is read from).
+usage: hbm_traffic_json.py <collect dir> <workload> <out.json> <tag> [boot]
+  (boot: the kernels of the batched bootstrap pass, collected on scripts/boot_passes.py)"""
 import collections, csv, json, re, sys
 
 root, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -19,23 +21,26 @@ def means(path):
 
 
 cal = means(f"{root}/cal/cal_counter_collection.csv")["k_stream"]
-tag = [a for a in sys.argv[4:]] or ["r01"]
+tag = [a for a in sys.argv[4:5]] or ["r01"]
+boot = len(sys.argv) > 5 and sys.argv[5] == "boot"
 rd = means(f"{root}/pf/{tag[0]}_counter_collection.csv")
 wr = means(f"{root}/pw/{tag[0]}_counter_collection.csv")
 factor = KNOWN_KB / cal
 kern = {}
-for k in ("k_em_tile", "k_remote_fold", "k_reldiff_swap_clear"):
+names = ("k_em_tile_e", "k_remote_fold_b", "k_reldiff_b") if boot else ("k_em_tile", "k_remote_fold", "k_reldiff_swap_clear")
+for k in names:
     kern[k] = {"read": rd[k] * 1024 * factor, "write": wr[k] * 1024}
 doc = {
     "workload": wl,
-    "command": f"python bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu-baseline --bootstraps 0",
+    "command": (f"python scripts/boot_passes.py {wl} 20  (4-slot batched passes, all slots running, one chain)" if boot else
+                f"python bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu-baseline --bootstraps 0 --cells 0"),
     "fetch_calibration": {
         "kernel": "scripts/microbench/stream (rows of 64 lanes, 4/8/12/16 B per lane)",
         "known_KB_per_launch": KNOWN_KB, "FETCH_SIZE_KB": cal, "factor": factor,
         "note": "gfx950 FETCH_SIZE counts 64 B per 128 B request (MI355X_MICROARCH.md, HBM section): corrected "
                 "bytes = FETCH_SIZE*1024*factor; WRITE_SIZE is taken as reported (uncalibrated)"},
     "per_launch_bytes": kern,
-    "per_pass_bytes_total": sum(v["read"] + v["write"] for v in kern.values()),
+    ("per_batched_pass_bytes_total" if boot else "per_pass_bytes_total"): sum(v["read"] + v["write"] for v in kern.values()),
 }
 json.dump(doc, open(out, "w"), indent=1)
-print(json.dumps(doc["per_launch_bytes"]), doc["per_pass_bytes_total"])
+print(json.dumps(doc["per_launch_bytes"]), sum(v["read"] + v["write"] for v in kern.values()))
