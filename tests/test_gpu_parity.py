@@ -1163,6 +1163,37 @@ def test_hot_transcripts_do_not_break_the_layout():
         assert cnt[0] == 1000.0
 
 
+@pytest.mark.parametrize("coverage", [False, True])
+def test_store_wider_than_the_packed_transcript_field(coverage):
+    """A remote record packs (transcript - problem base) into 22 bits next to the read index
+    (oem_layout_pack.hip); a store with more than 2^22 transcripts keeps (transcript u32, read u16) and only
+    loses the slot stream -- the other instantiation of every tile kernel.  Point estimate, m-step with
+    multiplicities, batched and one-per-pass bootstraps against the oracle, f32 and f64 weights."""
+    from oarfish_amd import _lib
+    T = (1 << 22) + 12_345
+    st = synth.make_store(60_000, T, seed=909, coverage=coverage)
+    assert st.tid.max() >= (1 << 22)
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T) as d:
+        rng = np.random.default_rng(4)
+        theta = rng.uniform(0.0, 3.0, T)
+        w = rng.integers(0, 4, st.n_reads).astype(np.uint32)
+        assert_counts_close(d.m_step(theta, w), c_oracle.m_step(o, theta, row_w=w), st.n_reads, T, 1e-10, "m-step")
+        got, gi = d.em_run(None, 80, 1e-3, 50)
+        want, wi = c_oracle.do_em(o, max_iter=80, conv_thresh=1e-3)
+        assert abs(gi.niter - wi.niter) <= 1
+        assert_counts_close(got, want, st.n_reads, T, RTOL if gi.niter != wi.niter else 1e-9, "wide store")
+        W = np.stack([d.bootstrap_weights(3, b) for b in range(3)])
+        for batch in (1, 0):
+            d.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, batch)
+            boots, binfo = d.bootstrap(3, row_w_all=W, max_iter=70)
+            for b in range(3):
+                wb, wbi = c_oracle.do_em(o, max_iter=70, conv_thresh=1e-3, row_w=W[b])
+                assert abs(binfo[b].niter - wbi.niter) <= 1
+                assert_counts_close(boots[b], wb, st.n_reads, T, RTOL if binfo[b].niter != wbi.niter else 1e-9,
+                                    f"wide store, bootstrap {b}, batch={batch}")
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_batched_bootstrap_fuzz_random_shapes_match_oracle(seed):
     """The batch kernels (k_em_tile_e / k_remote_fold_b / k_reldiff_b, two chains) over randomly shaped stores:
