@@ -64,3 +64,27 @@ def test_bench_forced_dist_path_under_torchrun():
     _check_contract(d, 6, 2)
     assert "forced dist path" in d["config"]["parallelism"]
     assert "replica-parallel" in d["bootstraps"]["mode"] and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_device_over_p2p():
+    """The N > 1 bench with N = 2 REAL ranks: two processes under torch.distributed.run, both on cuda:0
+    (`--same-device`: gloo process group, nnz-balanced row shards, the count vector exchanged peer to peer over
+    hipIpc-mapped buffers inside the rel-diff kernel, replica-parallel bootstraps, dealt cells, max-over-ranks
+    timing) -- every collective step of what an 8-GPU node executes, short of RCCL and xGMI."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "tiny",
+           "--steps", "6", "--warmup", "2", "--bootstraps", "3", "--cells", "4", "--no-cpu-baseline", "--same-device"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "row-shard x2" in d["config"]["parallelism"] and "ONE device" in d["config"]["parallelism"]
+    ex = d["config"]["exchange"]
+    assert ex["p2p_connected"] and ex["allreduce_us"] > 0
+    assert d["bootstraps"]["n"] == 6 and d["bootstraps"]["value"] > 0 and "replica-parallel over 2" in d["bootstraps"]["mode"]
+    assert d["cells"]["n_cells"] == 8 and d["cells"]["worst_mass_error"] < 1e-6 * d["cells"]["reads_per_cell"]
+    for name in ("em", "em_par"):   # the sharded loop converges like the un-sharded one (tiny store: a handful of passes)
+        assert d["em_to_convergence"][name]["n_passes"] >= 3
+    assert d["roofline"] and d["cpu_baseline"] is None

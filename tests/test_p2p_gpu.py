@@ -145,3 +145,37 @@ def test_p2p_argument_checks():
             assert ei.value.code == _lib.OEM_ERR_STATE
     finally:
         L.oem_comm_destroy(h)
+
+
+@pytest.mark.timeout(120)
+def test_a_peer_that_never_arrives_is_an_error_not_a_hang():
+    """Two ranks are connected, only rank 0 runs: its wait for rank 1's flag is bounded (8 s of wall clock on the
+    device), sets the error flag, later launches of the run stop waiting, and the host reports OEM_ERR_STATE."""
+    import time
+    L = _lib.lib()
+    comms = []
+    for r in range(2):
+        h = C.c_void_p()
+        _lib.check(L.oem_comm_create(None, r, 2, 0, C.byref(h)))
+        comms.append(h)
+    try:
+        blobs = bytearray()
+        for r in range(2):
+            b = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+            _lib.check(L.oem_comm_p2p_export(comms[r], 400, C.addressof(b)))
+            blobs += bytes(b)
+        for r in range(2):
+            _lib.check(L.oem_comm_p2p_connect(comms[r], bytes(blobs)))
+        st = synth.make_store(6_000, 400, seed=8)
+        sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, 0, 2)
+        with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps) as d:
+            d.attach_comm(comms[0], st.n_reads, sh.row_begin)
+            t = time.perf_counter()
+            with pytest.raises(_lib.OemError) as ei:
+                d.em_run(None, 200, 1e-3, 50)
+            dt = time.perf_counter() - t
+            assert ei.value.code == _lib.OEM_ERR_STATE and "did not arrive" in str(ei.value)
+            assert 7.0 < dt < 40.0, dt     # one bounded wait, not one per launch
+    finally:
+        for h in comms:
+            L.oem_comm_destroy(h)
