@@ -22,6 +22,19 @@ namespace {
 
 constexpr int kFoldThreads = 1024;
 
+// Phase timestamps of k_em_tile (test-only library): wave 0 of every workgroup stamps the device wall clock
+// (100 MHz) at its phase boundaries into g_tile_probe[tile][16] -- scripts/tile_probe.py turns them into the
+// per-phase account of profiles/r03_notes.md.  The product build has no probe code at all.
+#ifdef OEM_TESTING
+__device__ unsigned long long *g_tile_probe = nullptr;
+#define OEM_PROBE(i)                                                                                          \
+    do {                                                                                                      \
+        if (g_tile_probe && threadIdx.x == 0) g_tile_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define OEM_PROBE(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lds_add_f64(double *p, double v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_f64
@@ -181,6 +194,96 @@ __device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, cons
     }
 }
 
+// The FIRST slice of a wavefront is the widest of its four (a tile's reads are ordered by local-alignment
+// count and dealt to the wavefronts round-robin), and at 8 alignments per read on average it is wider than the
+// kCh = 8 a register set holds: its alignments 8..15 used to go through the reload loops of fold_slice -- two
+// synchronous loads per alignment in the middle of the fold, each wait also draining the prefetch of the next
+// slice.  In-kernel timestamps (scripts/tile_probe.py, profiles/r03_notes.md) put 7.8 us of a tile's 26 us
+// there.  Both register sets are idle until the local phase begins, so the first slice's alignments 8..15 are
+// loaded into the SECOND set with everything else at the top of the kernel (hidden behind the remote phases);
+// the fold runs over 16 register-resident alignments, hands the first set to the next slice's prefetch as
+// soon as its own scatter is done with it, and only reads with more than 16 local alignments reload.
+template <typename WT, int kCh, int kCopies, bool kNT>
+__device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRegs<WT, kCh> &hi, uint32_t width, uint32_t s,
+                                           uint32_t lane, const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase,
+                                           const TileDesc &td, const double *theta_l, double *cnt_l, double *den_l,
+                                           const uint32_t *__restrict__ row_w_perm, bool prefetch_next,
+                                           const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width)
+{
+    const uint32_t rl = s * 64 + lane;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
+#pragma unroll
+    for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(lo.c[k]), "v"(hi.c[k]));
+    // (load_slice zero-fills beyond the width; the second element of the last pair of an odd width belongs to
+    // the next row and must carry no weight)
+    double x[kCh];
+    double denom = den_l[rl];
+#pragma unroll
+    for (int k = 0; k < kCh; ++k) {
+        const WT wk = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : lo.w[k];
+        const uint32_t off = (k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu);
+        x[k] = lds_ld(theta_l, off) * (double)wk;                            // em.rs:111
+        denom += x[k];
+    }
+    if (width > (uint32_t)kCh) { // wave-uniform
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) {
+            const WT wk = ((k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : hi.w[k];
+            const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
+            denom += lds_ld(theta_l, off) * (double)wk;
+        }
+    }
+    for (uint32_t j = 2 * kCh; j < width; ++j) { // reads with more than 16 local alignments
+        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        denom += lds_ld(theta_l, off) * (double)wbase[j * 64 + lane];
+    }
+    double scale = 1.0;
+    if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
+    const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
+    den_l[rl] = inv;
+    const uint32_t copy_off = (lane % kCopies) * 8u;
+    {
+        const uint32_t off0 = lo.c[0] & 0xffffu;
+        const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
+        const double v0 = x[0] * inv;
+        if (__all(off0 == u)) {
+            const double sum = wave_sum_f64(v0);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
+        } else if (v0 != 0.0) {
+            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
+        }
+    }
+#pragma unroll
+    for (int k = 1; k < kCh; ++k) {
+        if ((uint32_t)k < width) { // uniform
+            const uint32_t off = (k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu);
+            const double v = x[k] * inv;
+            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        }
+    }
+    // the first register set is done: the next slice's loads go out now, under the rest of this fold
+    if (prefetch_next) load_slice<WT, kCh, kNT>(lo, next_w, next_c, lane, next_width);
+    if (width > (uint32_t)kCh) {
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) {
+            if ((uint32_t)(k + kCh) < width) { // uniform
+                const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
+                const double v = lds_ld(theta_l, off) * (double)hi.w[k] * inv;
+                if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            }
+        }
+    }
+    for (uint32_t j = 2 * kCh; j < width; ++j) {
+        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
+        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
+        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+    }
+}
+
 template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
@@ -191,6 +294,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const BatchState *__restrict__ problems, uint32_t problem_size)
 {
     if (state && state->done) return;
+    OEM_PROBE(0);
 
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
@@ -221,12 +325,25 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         }
     }
 
+    OEM_PROBE(1); // descriptor in hand, slice addresses derived
     // ---- every long-latency load of the tile is issued here, before any use ---------
     // The first slice of the wavefront is loaded here; the rest are prefetched one slice ahead of
     // the fold (two register sets, ping-pong).
-    constexpr uint32_t kSets = kPerWave > 1 ? 2 : 1;
+    constexpr uint32_t kSets = 2;
+    // the theta window depends on the descriptor alone: its loads go out first, so that (loads return in
+    // order) waiting for them waits for nothing else
+    constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
+    double tw[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t i = tx + u * kTileThreads;
+        tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
+    }
     SliceRegs<WT, kCh> R[kSets];
     load_slice<WT, kCh, kNT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+    // alignments 8..15 of the first slice, into the second set (see fold_first)
+    load_slice<WT, kCh, kNT>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
+                             wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -256,30 +373,29 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         }
 #pragma unroll
         for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
-        // the slots are wanted last (phase B): a few words per tile, cache-resident, off the critical path
+        // the slots are wanted last (phase B): a few words per tile, cache-resident.  Branch-free and back to
+        // back -- a lookup per branch made the compiler wait for each one in turn, six dependent round trips
+        // (a tile without remote records reads the table's slack word)
+        uint32_t sdv[kRem];
+#pragma unroll
+        for (int k = 0; k < kRem; ++k) sdv[k] = sd_t[rt[k] >> kBucketShift];
+        const uint32_t last_i = td.remote_cnt ? td.remote_cnt - 1 : 0u;
 #pragma unroll
         for (int k = 0; k < kRem; ++k) {
             const uint32_t i = tx + k * kTileThreads;
-            rslot[k] = td.remote_cnt ? sd_t[rt[k] >> kBucketShift] + (i < td.remote_cnt ? i : td.remote_cnt - 1) : 0u;
+            rslot[k] = sdv[k] + (i < td.remote_cnt ? i : last_i);
         }
     }
-    {
-        constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
-        double tw[kPer];
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = tx + u * kTileThreads;
-            tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = tx + u * kTileThreads;
-            if (i < td.win_len) theta_l[i] = tw[u];
-        }
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t i = tx + u * kTileThreads;
+        if (i < td.win_len) theta_l[i] = tw[u];
     }
     for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
+    OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
     __syncthreads();
+    OEM_PROBE(3);
 
     // ---- remote alignments, phase A: denominators --------------------------------
 #pragma unroll
@@ -293,20 +409,34 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         queue[sd_t[t >> kBucketShift] + i] = x;
         lds_add_f64(&den_l[row], x);
     }
+    OEM_PROBE(4); // remote gathers landed, their denominator atomics issued
     __syncthreads();
+    OEM_PROBE(5);
 
     // ---- local alignments: one read per lane, all operands already in registers -----
+    // slice 0: 16 register-resident alignments in both sets; it releases R[0] to slice 1's prefetch half way
+    if (wave < td.n_slices)
+        fold_first<WT, kCh, kCopies, kNT>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
+                                          td, theta_l, cnt_l, den_l, row_w_perm, kPerWave > 1,
+                                          w + (size_t)woff[kPerWave > 1 ? 1 : 0] * 64, codes + (size_t)coff[kPerWave > 1 ? 1 : 0] * 64,
+                                          wid[kPerWave > 1 ? 1 : 0]);
+    else if (kPerWave > 1)
+        load_slice<WT, kCh, kNT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
+    OEM_PROBE(6);
+    // slices 1..: slice q sits in R[(q - 1) % 2], slice q + 1 is prefetched into the other set
 #pragma unroll
-    for (uint32_t q = 0; q < kPerWave; ++q) {
+    for (uint32_t q = 1; q < kPerWave; ++q) {
         const uint32_t s = wave + kWaves * q;
         if (q + 1 < kPerWave)
-            load_slice<WT, kCh, kNT>(R[(q + 1) % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+            load_slice<WT, kCh, kNT>(R[q % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies>(R[q % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+            fold_slice<WT, kCh, kCopies>(R[(q - 1) % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
                        theta_l, cnt_l, den_l, row_w_perm);
+        OEM_PROBE(6 + q); // wave 0's slice q folded (its operands had to land first)
     }
     __syncthreads();
+    OEM_PROBE(10);
 
     // ---- remote alignments, phase B: queue <- x * (c_i / denom_i) ------------------
 #pragma unroll
@@ -329,6 +459,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
         if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
+    OEM_PROBE(11); // queue stores and window flush issued
 }
 
 __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
@@ -475,3 +606,35 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 }
 
 } // namespace oem
+
+#ifdef OEM_TESTING
+// Test hook: one probed E/M pass (after an unprobed one); out = n_tiles x 16 wall-clock stamps (100 MHz).
+extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint64_t n_out)
+{
+    using namespace oem;
+    OEM_API_BEGIN
+    if (!s || !out || !s->tiled.present || n_out < (uint64_t)s->tiled.n_tiles * 16)
+        return fail(OEM_ERR_ARG, "oem_debug_tile_probe: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_HIP(hipSetDevice(s->device));
+    const size_t n = (size_t)s->tiled.n_tiles * 16;
+    unsigned long long *d = nullptr;
+    OEM_HIP(hipMalloc((void **)&d, n * sizeof(unsigned long long)));
+    OEM_HIP(hipMemset(d, 0, n * sizeof(unsigned long long)));
+    const uint32_t T = s->csr.n_txps;
+    OEM_TRY(launch_fill(s, s->theta, (double)s->global_n_reads / (double)T, T));
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr));   // warm
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &d, sizeof(d)));
+    int rc = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr);
+    hipStreamSynchronize(s->stream);
+    unsigned long long *null = nullptr;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &null, sizeof(null));
+    if (rc == OEM_OK && hipMemcpy(out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(OEM_ERR_HIP, "oem_debug_tile_probe: read-back failed");
+    hipFree(d);
+    return rc;
+    OEM_API_END("oem_debug_tile_probe")
+}
+#endif
