@@ -91,6 +91,31 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__rest
         if ((uint32_t)k >= width) r.w[k] = (WT)0;
 }
 
+// Alignments beyond the kBCh a register set holds are reloaded by both passes of the fold.  One alignment at a
+// time that is two synchronous loads per alignment (the widest slice of a tile has ~8 of them, and the
+// wavefront that owns it holds up the tile's barriers); four at a time it is one round trip per four.  Rows
+// past the slice's width are clamped to its last row and carry no weight.
+template <typename WT>
+__device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase, uint32_t lane,
+                                           uint32_t i0 /* even */, uint32_t width, WT wv[4], uint32_t off[4])
+{
+    const uint32_t lastp = (width - 1) >> 1;
+    const uint32_t p0 = i0 >> 1, p1 = p0 + 1 <= lastp ? p0 + 1 : lastp;
+    const uint32_t c0 = cbase[p0 * 64 + lane], c1 = cbase[p1 * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const uint32_t i = i0 + m;
+        wv[m] = wbase[(i < width ? i : width - 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (i0 + m >= width) wv[m] = (WT)0;
+    off[0] = (c0 & 0xffffu) * kEB;
+    off[1] = (c0 >> 16) * kEB;
+    off[2] = (c1 & 0xffffu) * kEB;
+    off[3] = (c1 >> 16) * kEB;
+}
+
 // LDS layouts of one epoch (b = slot inside the epoch, c = window entry, r = read of the tile):
 //   theta_l, cnt_l : [c][b]  byte (c * kEB + b) * 8 = code * kEB + b * 8   (code = 8 c, as stored)
 //   den_l          : [b][r]  remote part of the denominators, then c_ib / denom_ib
@@ -175,10 +200,14 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             rw[k] = ld_stream_b<kNT>(&r_w[o]);
         }
     }
+    {   // branch-free and back to back (a lookup per branch is a dependent round trip each); a thread without a
+        // record reads the tile's first table word (or the table's slack word when the tile has no records)
+        uint32_t sdv[kRemE];
 #pragma unroll
-    for (int k = 0; k < kRemE; ++k) {
-        const uint32_t i = tx + k * kTileThreadsE;
-        if (i < td.remote_cnt) rslot[k] = sd_t[rt[k] >> kBucketShift] + i;
+        for (int k = 0; k < kRemE; ++k)
+            sdv[k] = sd_t[tx + k * kTileThreadsE < td.remote_cnt ? rt[k] >> kBucketShift : td.b_min];
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k) rslot[k] = sdv[k] + tx + k * kTileThreadsE;
     }
     // slot of this lane at step j of an epoch: (j + lane) mod kEB
     uint32_t rot8[kEB]; // byte offset of that slot inside a [c][b] window entry
@@ -288,12 +317,16 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                 for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
                 if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
             }
-            for (uint32_t i = kBCh; i < width; ++i) { // reads with more than kBCh local alignments
-                const uint32_t cc = cbase[(i >> 1) * 64 + lane];
-                const uint32_t off = ((i & 1) ? (cc >> 16) : (cc & 0xffffu)) * kEB;
-                const double wk = (double)wbase[i * 64 + lane];
+            for (uint32_t i0 = kBCh; i0 < width; i0 += 4) { // reads with more than kBCh local alignments
+                WT wv[4];
+                uint32_t off4[4];
+                load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
 #pragma unroll
-                for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
+                for (int m = 0; m < 4; ++m) {
+                    const double wk = (double)wv[m];
+#pragma unroll
+                    for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off4[m] + rot8[j]) * wk;
+                }
             }
             double inv[kEB];
 #pragma unroll
@@ -321,14 +354,18 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            for (uint32_t i = kBCh; i < width; ++i) {
-                const uint32_t cc = cbase[(i >> 1) * 64 + lane];
-                const uint32_t off = ((i & 1) ? (cc >> 16) : (cc & 0xffffu)) * kEB;
-                const double wk = (double)wbase[i * 64 + lane];
+            for (uint32_t i0 = kBCh; i0 < width; i0 += 4) {
+                WT wv[4];
+                uint32_t off4[4];
+                load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
 #pragma unroll
-                for (int j = 0; j < kEB; ++j) {
-                    const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
-                    if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
+                for (int m = 0; m < 4; ++m) {
+                    const double wk = (double)wv[m];
+#pragma unroll
+                    for (int j = 0; j < kEB; ++j) {
+                        const double v = lds_ld_b(theta_l, off4[m] + rot8[j]) * wk * inv[j];
+                        if (v != 0.0) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
+                    }
                 }
             }
         }
