@@ -32,7 +32,7 @@ SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_
            "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_layout_pack.hip", "oem_coverage_device.hip",
            "oem_builder.cpp", "oem_comm.cpp", "oem_p2p.hip", "oem_knobs.cpp"]
 # the testing library swaps these for their -DOEM_TESTING build and adds the hooks
-TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip"]
+TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip", "oem_batch_kernels.hip"]
 TESTING_ONLY = ["oem_testing.hip"]
 HEADERS = ["oem_internal.h", "oem_layout.h", os.path.join(INCLUDE, "oarfish_em.h")]
 
@@ -102,7 +102,7 @@ def _compile(src: str, testing: bool, verbose: bool) -> None:
 
 
 TESTING_HOOKS = ["oem_debug_layout_hash", "oem_debug_local_comm_create", "oem_test_reldiff_stress", "oem_debug_knob",
-                 "oem_debug_tile_probe"]
+                 "oem_debug_tile_probe", "oem_debug_tile_e_probe_begin", "oem_debug_tile_e_probe_end"]
 
 
 def header_symbols() -> list:

@@ -33,6 +33,17 @@ namespace oem {
 
 namespace {
 
+// phase timestamps of k_em_tile_e (test-only library; see OEM_PROBE in oem_tile_kernels.hip)
+#ifdef OEM_TESTING
+__device__ unsigned long long *g_tile_e_probe = nullptr;
+#define OEM_PROBE_E(i)                                                                                            \
+    do {                                                                                                          \
+        if (g_tile_e_probe && threadIdx.x == 0) g_tile_e_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define OEM_PROBE_E(i) do { } while (0)
+#endif
+
 constexpr int kB = kBatch;
 constexpr int kEB = 4;             // slots per epoch
 constexpr int kE = kB / kEB;       // epochs per pass
@@ -116,6 +127,111 @@ __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const u
     off[3] = (c1 >> 16) * kEB;
 }
 
+// The fold of one slice for the four slots of an epoch: denominators (pass 1), c_ib / denom_ib, scatter (pass 2,
+// which derives its LDS addresses again from the packed operands: that keeps the kernel inside 128 VGPRs).
+// kHasHi: the slice's alignments 8..15 sit in a second register set (`hi`) -- the widest slice of the
+// wavefront, see fold_first in oem_tile_kernels.hip; the first set is handed to the NEXT slice's loads as soon
+// as the scatter is done with it (`next_*`).  Alignments beyond the register-resident ones are reloaded four at
+// a time by both passes.
+template <typename WT, bool kNT, bool kHasHi>
+__device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, const SliceRegsB<WT> &hi, uint32_t width, uint32_t mq,
+                                             uint32_t rl, uint32_t lane, const WT *__restrict__ wbase,
+                                             const uint32_t *__restrict__ cbase, const double *theta_l, double *cnt_l,
+                                             double *den_l, const uint32_t (&rot8)[kEB], uint32_t act_e, bool load_next,
+                                             const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c,
+                                             uint32_t next_width)
+{
+    constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
+    double denom[kEB];
+#pragma unroll
+    for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
+#pragma unroll
+    for (int k = 0; k < kBCh; ++k) {
+        const uint32_t off = ((k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu)) * kEB;
+        const double wk = (double)lo.w[k];
+#pragma unroll
+        for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
+        if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
+    }
+    if (kHasHi && width > (uint32_t)kBCh) { // wave-uniform
+#pragma unroll
+        for (int k = 0; k < kBCh; ++k) {
+            const uint32_t off = ((k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu)) * kEB;
+            const double wk = (double)hi.w[k];
+#pragma unroll
+            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (uint32_t i0 = kReg; i0 < width; i0 += 4) { // reads with more alignments than the registers hold
+        WT wv[4];
+        uint32_t off4[4];
+        load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double wk = (double)wv[m];
+#pragma unroll
+            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off4[m] + rot8[j]) * wk;
+        }
+    }
+    double inv[kEB];
+#pragma unroll
+    for (int j = 0; j < kEB; ++j) {
+        const uint32_t b = rot8[j] >> 3;
+        const double scale = (double)((mq >> (8 * b)) & 0xffu);
+        inv[j] = (((act_e >> b) & 1u) && denom[j] > OEM_EM_DENOM_THRESH) ? scale / denom[j] : 0.0; // em.rs:115
+        den_l[b * kTileRows + rl] = inv[j];
+    }
+#pragma unroll
+    for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(lo.w[k]));
+#pragma unroll
+    for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(lo.c[k]));
+#pragma unroll
+    for (int k = 0; k < kBCh; ++k) {
+        if ((uint32_t)k < width) { // wave-uniform
+            const uint32_t off = ((k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu)) * kEB;
+            const double wk = (double)lo.w[k];
+#pragma unroll
+            for (int j = 0; j < kEB; ++j) {
+                const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first set is free: the next slice's loads go out under the rest of this fold
+    if (kHasHi && load_next) load_slice_b<kNT, WT>(lo, next_w, next_c, lane, next_width);
+    if (kHasHi && width > (uint32_t)kBCh) {
+#pragma unroll
+        for (int k = 0; k < kBCh; ++k) {
+            if ((uint32_t)(k + kBCh) < width) { // wave-uniform
+                const uint32_t off = ((k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu)) * kEB;
+                const double wk = (double)hi.w[k];
+#pragma unroll
+                for (int j = 0; j < kEB; ++j) {
+                    const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                    if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (uint32_t i0 = kReg; i0 < width; i0 += 4) {
+        WT wv[4];
+        uint32_t off4[4];
+        load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double wk = (double)wv[m];
+#pragma unroll
+            for (int j = 0; j < kEB; ++j) {
+                const double v = lds_ld_b(theta_l, off4[m] + rot8[j]) * wk * inv[j];
+                if (v != 0.0) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
+            }
+        }
+    }
+}
+
 // LDS layouts of one epoch (b = slot inside the epoch, c = window entry, r = read of the tile):
 //   theta_l, cnt_l : [c][b]  byte (c * kEB + b) * 8 = code * kEB + b * 8   (code = 8 c, as stored)
 //   den_l          : [b][r]  remote part of the denominators, then c_ib / denom_ib
@@ -153,6 +269,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         fin |= (ph == kPhaseFinal) ? (1u << b) : 0u;
     }
     if (!act) return;
+    OEM_PROBE_E(0);
 
     __shared__ double theta_l[kWin * kEB];
     __shared__ double cnt_l[kWin * kEB];
@@ -165,13 +282,16 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);
 
+    // slices come in descending width: wavefront w takes slice w and slice 15 - w (the widest with the
+    // narrowest), not w and w + 8 -- the tile's barriers wait for the wavefront with the most rows
+    auto slice_of = [&](uint32_t q) -> uint32_t { return (q & 1u) ? (q + 1) * kWaves - 1 - wave : q * kWaves + wave; };
     uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
     {
         uint32_t accw = td.w_base, accc = td.c_base;
 #pragma unroll
         for (uint32_t i = 0; i < kTileSlices; ++i) {
             const uint32_t wi = td.width[i];
-            if ((i % kWaves) == wave) {
+            if (i == slice_of(i / kWaves)) {
                 woff[i / kWaves] = accw;
                 coff[i / kWaves] = accc;
                 wid[i / kWaves] = wi;
@@ -181,11 +301,22 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         }
     }
 
+    OEM_PROBE_E(1);
     // ---- the tile's matrix data, loaded once and kept in registers over all epochs ----------
+    // One epoch (kBatch = 4, what ships): the second register set first holds alignments 8..15 of the wavefront's
+    // first -- widest -- slice, and its second slice is loaded into the first set half way through that fold
+    // (fold_slice_e).  Builds with several epochs keep both slices resident over all of them.
+    constexpr bool kHandOver = kE == 1 && kPerWave == 2;
     SliceRegsB<WT> R[kPerWave];
+    load_slice_b<kNT, WT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+    if (kHandOver) {
+        load_slice_b<kNT, WT>(R[1], w + ((size_t)woff[0] + kBCh) * 64, codes + ((size_t)coff[0] + kBCh / 2) * 64, lane,
+                              wid[0] > (uint32_t)kBCh ? wid[0] - kBCh : 0u);
+    } else {
 #pragma unroll
-    for (uint32_t q = 0; q < kPerWave; ++q)
-        load_slice_b<kNT, WT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+        for (uint32_t q = 1; q < kPerWave; ++q)
+            load_slice_b<kNT, WT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+    }
     uint32_t rt[kRemE], rrow[kRemE], rslot[kRemE];
     WT rw[kRemE];
     const uint32_t tid_base = td.problem * problem_size;
@@ -228,7 +359,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         uint32_t mult[kPerWave];
 #pragma unroll
         for (uint32_t q = 0; q < kPerWave; ++q) {
-            const uint32_t rl = (wave + kWaves * q) * 64 + lane;
+            const uint32_t rl = slice_of(q) * 64 + lane;
             mult[q] = rl < td.n_rows ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff) : 0u;
         }
         // multiplicities of the reads of this thread's remote records (4 KB per tile: cache-resident).  A read
@@ -255,7 +386,9 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
             for (int b = 0; b < kEB; ++b) den_l[b * kTileRows + i] = 0.0;
         }
+        OEM_PROBE_E(2);
         __syncthreads();
+        OEM_PROBE_E(3);
 
         // ---- remote phase A: denominators ------------------------------------------------
 #pragma unroll
@@ -279,97 +412,52 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                 lds_add(&den_l[b * kTileRows + row], x);
             }
         }
+        OEM_PROBE_E(4);
         __syncthreads();
+        OEM_PROBE_E(5);
 
         // ---- local alignments: one read per lane, slots in rotated order ---------------------
-        // (one slice at a time, not interleaved: the slices' operands are already in registers and the
-        // second pass recomputes its LDS addresses, which keeps the kernel inside 128 VGPRs)
+        if (kHandOver) {
+            const uint32_t s0 = slice_of(0), s1 = slice_of(1);
+            if (s0 < td.n_slices)
+                fold_slice_e<WT, kNT, true>(R[0], R[1], wid[0], mult[0], s0 * 64 + lane, lane, w + (size_t)woff[0] * 64,
+                                            codes + (size_t)coff[0] * 64, theta_l, cnt_l, den_l, rot8, act_e, true,
+                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1]);
+            else
+                load_slice_b<kNT, WT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
+            OEM_PROBE_E(6);
+            if (s1 < td.n_slices)
+                fold_slice_e<WT, kNT, false>(R[0], R[0], wid[1], mult[1], s1 * 64 + lane, lane, w + (size_t)woff[1] * 64,
+                                             codes + (size_t)coff[1] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
+                                             nullptr, nullptr, 0u);
+            OEM_PROBE_E(7);
+        } else {
 #pragma unroll 1
-        for (uint32_t q = 0; q < kPerWave; ++q) {
-            const uint32_t s = wave + kWaves * q;
-            if (s >= td.n_slices) continue;
-            SliceRegsB<WT> cur;
-            uint32_t width = wid[0], mq = mult[0], wo = woff[0], co = coff[0];
+            for (uint32_t q = 0; q < kPerWave; ++q) {
+                const uint32_t s = slice_of(q);
+                if (s >= td.n_slices) continue;
+                SliceRegsB<WT> cur;
+                uint32_t width = wid[0], mq = mult[0], wo = woff[0], co = coff[0];
 #pragma unroll
-            for (int k = 0; k < kBCh; ++k) cur.w[k] = R[0].w[k];
+                for (int k = 0; k < kBCh; ++k) cur.w[k] = R[0].w[k];
 #pragma unroll
-            for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[0].c[k];
+                for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[0].c[k];
 #pragma unroll
-            for (uint32_t qq = 1; qq < kPerWave; ++qq)
-                if (q == qq) { // wave-uniform
-                    width = wid[qq]; mq = mult[qq]; wo = woff[qq]; co = coff[qq];
+                for (uint32_t qq = 1; qq < kPerWave; ++qq)
+                    if (q == qq) { // wave-uniform
+                        width = wid[qq]; mq = mult[qq]; wo = woff[qq]; co = coff[qq];
 #pragma unroll
-                    for (int k = 0; k < kBCh; ++k) cur.w[k] = R[qq].w[k];
+                        for (int k = 0; k < kBCh; ++k) cur.w[k] = R[qq].w[k];
 #pragma unroll
-                    for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[qq].c[k];
-                }
-            const uint32_t rl = s * 64 + lane;
-            const WT *wbase = w + (size_t)wo * 64;
-            const uint32_t *cbase = codes + (size_t)co * 64;
-            double denom[kEB];
-#pragma unroll
-            for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
-#pragma unroll
-            for (int k = 0; k < kBCh; ++k) {
-                const uint32_t off = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) * kEB;
-                const double wk = (double)cur.w[k];
-#pragma unroll
-                for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
-                if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
-            }
-            for (uint32_t i0 = kBCh; i0 < width; i0 += 4) { // reads with more than kBCh local alignments
-                WT wv[4];
-                uint32_t off4[4];
-                load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double wk = (double)wv[m];
-#pragma unroll
-                    for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off4[m] + rot8[j]) * wk;
-                }
-            }
-            double inv[kEB];
-#pragma unroll
-            for (int j = 0; j < kEB; ++j) {
-                const uint32_t b = rot8[j] >> 3;
-                const double scale = (double)((mq >> (8 * b)) & 0xffu);
-                inv[j] = (((act_e >> b) & 1u) && denom[j] > OEM_EM_DENOM_THRESH) ? scale / denom[j] : 0.0; // em.rs:115
-                den_l[b * kTileRows + rl] = inv[j];
-            }
-            // the second pass derives its addresses and weights again from the packed operands
-#pragma unroll
-            for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(cur.w[k]));
-#pragma unroll
-            for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(cur.c[k]));
-#pragma unroll
-            for (int k = 0; k < kBCh; ++k) {
-                if ((uint32_t)k < width) { // wave-uniform
-                    const uint32_t off = ((k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu)) * kEB;
-                    const double wk = (double)cur.w[k];
-#pragma unroll
-                    for (int j = 0; j < kEB; ++j) {
-                        const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
-                        if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
+                        for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[qq].c[k];
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (uint32_t i0 = kBCh; i0 < width; i0 += 4) {
-                WT wv[4];
-                uint32_t off4[4];
-                load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double wk = (double)wv[m];
-#pragma unroll
-                    for (int j = 0; j < kEB; ++j) {
-                        const double v = lds_ld_b(theta_l, off4[m] + rot8[j]) * wk * inv[j];
-                        if (v != 0.0) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
-                    }
-                }
+                fold_slice_e<WT, kNT, false>(cur, cur, width, mq, s * 64 + lane, lane, w + (size_t)wo * 64,
+                                             codes + (size_t)co * 64, theta_l, cnt_l, den_l, rot8, act_e, false, nullptr,
+                                             nullptr, 0u);
             }
         }
         __syncthreads();
+        OEM_PROBE_E(8);
 
         // ---- remote phase B: queue[slot][.] <- x_b * (c_ib / denom_ib) -------------------------
 #pragma unroll
@@ -397,6 +485,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             const double v = cnt_l[i];
             if (v != 0.0) unsafeAtomicAdd(&cnt[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], v);
         }
+        OEM_PROBE_E(9);
         if (e + 1 < kE) __syncthreads(); // the next epoch re-initialises the windows
     }
 }
@@ -643,3 +732,35 @@ int launch_batch_pack_row_w(oem_store *s, const uint32_t *d_row_w, const BatchBu
 }
 
 } // namespace oem
+
+#ifdef OEM_TESTING
+// Test hooks: route k_em_tile_e's phase stamps into a buffer (begin), fetch and release it (end).
+static unsigned long long *g_probe_e_buf = nullptr;
+static size_t g_probe_e_n = 0;
+extern "C" int oem_debug_tile_e_probe_begin(uint64_t n_tiles)
+{
+    using namespace oem;
+    OEM_API_BEGIN
+    if (g_probe_e_buf || n_tiles == 0) return fail(OEM_ERR_STATE, "oem_debug_tile_e_probe_begin: busy / empty");
+    g_probe_e_n = (size_t)n_tiles * 16;
+    OEM_HIP(hipMalloc((void **)&g_probe_e_buf, g_probe_e_n * sizeof(unsigned long long)));
+    OEM_HIP(hipMemset(g_probe_e_buf, 0, g_probe_e_n * sizeof(unsigned long long)));
+    OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_e_probe), &g_probe_e_buf, sizeof(g_probe_e_buf)));
+    return OEM_OK;
+    OEM_API_END("oem_debug_tile_e_probe_begin")
+}
+extern "C" int oem_debug_tile_e_probe_end(unsigned long long *out, uint64_t n_out)
+{
+    using namespace oem;
+    OEM_API_BEGIN
+    if (!g_probe_e_buf || !out || n_out < g_probe_e_n) return fail(OEM_ERR_ARG, "oem_debug_tile_e_probe_end: bad argument");
+    OEM_HIP(hipDeviceSynchronize());
+    unsigned long long *null = nullptr;
+    OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_e_probe), &null, sizeof(null)));
+    OEM_HIP(hipMemcpy(out, g_probe_e_buf, g_probe_e_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    hipFree(g_probe_e_buf);
+    g_probe_e_buf = nullptr;
+    return OEM_OK;
+    OEM_API_END("oem_debug_tile_e_probe_end")
+}
+#endif

@@ -306,7 +306,12 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6); // SGPR: slice control flow is scalar
     constexpr uint32_t kWaves = kTileThreads / 64;
-    constexpr uint32_t kPerWave = kTileSlices / kWaves; // slices per wavefront (round-robin: s = wave + kWaves*q)
+    constexpr uint32_t kPerWave = kTileSlices / kWaves; // slices per wavefront
+    // A tile's slices come in descending width, so dealing them round-robin gives wavefront 0 the widest of every
+    // group of kWaves (37 alignment rows against wavefront 3's 27 at 8 alignments per read) and the tile waits for
+    // it at the barrier.  Dealt boustrophedon -- wave, 2 kWaves - 1 - wave, 2 kWaves + wave, ... -- the widest
+    // slice still comes first (fold_first) and the sums are within a few rows of each other.
+    auto slice_of = [&](uint32_t q) -> uint32_t { return (q & 1u) ? (q + 1) * kWaves - 1 - wave : q * kWaves + wave; };
 
     // addresses of this wavefront's slices, from the widths alone (scalar prefix sums)
     uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
@@ -315,10 +320,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
         for (uint32_t i = 0; i < kTileSlices; ++i) {
             const uint32_t wi = td.width[i];
-            if ((i % kWaves) == wave) {
-                woff[i / kWaves] = accw;
-                coff[i / kWaves] = accc;
-                wid[i / kWaves] = wi;
+            const uint32_t q = i / kWaves; // the group of kWaves slices i belongs to: one of them is this wavefront's
+            if (i == slice_of(q)) {
+                woff[q] = accw;
+                coff[q] = accc;
+                wid[q] = wi;
             }
             accw += wi;
             accc += (wi + 1) >> 1;
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // slices 1..: slice q sits in R[(q - 1) % 2], slice q + 1 is prefetched into the other set
 #pragma unroll
     for (uint32_t q = 1; q < kPerWave; ++q) {
-        const uint32_t s = wave + kWaves * q;
+        const uint32_t s = slice_of(q);
         if (q + 1 < kPerWave)
             load_slice<WT, kCh, kNT>(R[q % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
                        wid[q + 1]);
