@@ -303,6 +303,18 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 
     OEM_PROBE_E(1);
     // ---- the tile's matrix data, loaded once and kept in registers over all epochs ----------
+    // the theta window of the (only) epoch depends on the descriptor alone: its loads go out before everything
+    // else, so that waiting for them waits for nothing else (loads return in order)
+    constexpr uint32_t kPerT = (kWin * kEB + kTileThreadsE - 1) / kTileThreadsE;
+    double tw0[kPerT];
+    if (kE == 1) {
+#pragma unroll
+        for (uint32_t u = 0; u < kPerT; ++u) {
+            const uint32_t i = tx + u * kTileThreadsE;
+            const uint32_t ic = i < td.win_len * kEB ? i : 0u;
+            tw0[u] = theta[((size_t)td.lo + ic / kEB) * kB + (ic % kEB)];
+        }
+    }
     // One epoch (kBatch = 4, what ships): the second register set first holds alignments 8..15 of the wavefront's
     // first -- widest -- slice, and its second slice is loaded into the first set half way through that fold
     // (fold_slice_e).  Builds with several epochs keep both slices resident over all of them.
@@ -379,8 +391,16 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
             for (int b = 0; b < kEB; ++b) rx[k][b] = th(tp[b], b) * (double)rw[k];
         }
-        for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE)
-            theta_l[i] = th(theta[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], i % kEB);
+        if (kE == 1) {
+#pragma unroll
+            for (uint32_t u = 0; u < kPerT; ++u) {
+                const uint32_t i = tx + u * kTileThreadsE;
+                if (i < td.win_len * kEB) theta_l[i] = th(tw0[u], i % kEB);
+            }
+        } else {
+            for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE)
+                theta_l[i] = th(theta[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], i % kEB);
+        }
         for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) cnt_l[i] = 0.0;
         for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreadsE) {
 #pragma unroll
