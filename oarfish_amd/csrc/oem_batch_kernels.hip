@@ -260,6 +260,8 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
 {
+    // (the descriptor is requested before the slots' states are looked at: scalar loads in flight together)
+    const TileDesc td = tiles[blockIdx.x];
     uint32_t act = 0; // slots that take part in this pass (RUNNING or FINAL)
     uint32_t fin = 0; // slots on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
 #pragma unroll
@@ -277,7 +279,6 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 
     constexpr uint32_t kWaves = kTileThreadsE / 64;
     constexpr uint32_t kPerWave = kTileSlices / kWaves;
-    const TileDesc td = tiles[blockIdx.x];
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);

@@ -70,17 +70,27 @@ __global__ __launch_bounds__(kRB) void k_reldiff_swap_clear(double *__restrict__
     if (state->done) return;
 
     double rel = 0.0; // em.rs:169 / :234: starts at 0 => negative diffs never win
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps;
-         i += gridDim.x * blockDim.x) {
-        const double pc = prev[i];
-        if (pc > OEM_MIN_READ_THRESH) {       // em.rs:195
-            const double cc = curr[i];
-            const double rd = (cc - pc) / pc; // em.rs:198 (signed)
-            rel = fmax(rel, rd);              // em.rs:199
+    // four elements per trip, all eight loads issued before the first use: the sweep is a handful of elements
+    // per thread, and one element per trip made it a chain of round trips
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < p.n_txps; i0 += 4 * stride) {
+        double pc[4], cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * stride;
+            const uint32_t ic = i < p.n_txps ? i : i0;
+            pc[k] = prev[ic];
+            cc[k] = curr[ic];
         }
-        const double cc2 = curr[i];
-        prev[i] = cc2;                        // em.rs:204 swap: prev_counts <- this pass's counts
-        curr[i] = 0.0;                        // em.rs:207 clear
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * stride;
+            if (i < p.n_txps) {
+                if (pc[k] > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc[k] - pc[k]) / pc[k]); // em.rs:195-199 (signed)
+                prev[i] = cc[k];              // em.rs:204 swap: prev_counts <- this pass's counts
+                curr[i] = 0.0;                // em.rs:207 clear
+            }
+        }
     }
     // wave64 max, then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));

@@ -293,14 +293,14 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
     const BatchState *__restrict__ problems, uint32_t problem_size)
 {
-    if (state && state->done) return;
-    OEM_PROBE(0);
-
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
+    OEM_PROBE(0);
+    // (the descriptor is requested before the run's state is looked at: two scalar loads in flight, not a chain)
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
+    if (state && state->done) return;
     if (problems && problems[td.problem].phase == kPhaseFinished) return; // per-cell batch: this cell is done
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
