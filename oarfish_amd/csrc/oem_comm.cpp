@@ -216,7 +216,12 @@ bool comm_exchange_is_unconditional(const Comm *c, uint32_t n_txps)
     return c && c->comm && !use_p2p(c, n_txps);
 }
 // after a stream synchronize: a peer-to-peer wait that timed out is reported, not hung on
-int comm_check(Comm *c, hipStream_t st) { return c && c->p2p ? p2p_check(c->p2p, st) : OEM_OK; }
+int comm_check(Comm *c, hipStream_t st)
+{
+    if (!c || !c->p2p) return OEM_OK;
+    if (c->comm && c->p2p_max_bytes == 0) return OEM_OK; // switched to RCCL alone (e.g. after a failed self check)
+    return p2p_check(c->p2p, st);
+}
 
 int comm_rank(const Comm *c) { return c ? c->rank : 0; }
 int comm_size(const Comm *c) { return c ? c->n_ranks : 1; }

@@ -76,6 +76,26 @@ def test_fails_loudly_without_a_device():
     assert rc == _lib.OEM_ERR_NO_DEVICE
 
 
+def test_p2p_communicator_without_a_device_fails_cleanly():
+    """A communicator that will exchange peer to peer is created without touching a device; allocating its
+    exchange buffer needs one: an error code, never a crash, and an unconnected multi-rank communicator
+    cannot be attached to a store."""
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.oem_comm_create(None, 0, 2, 0, C.byref(h)) == _lib.OEM_OK
+    try:
+        blob = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+        assert L.oem_comm_p2p_export(h, 0, C.addressof(blob)) == _lib.OEM_ERR_ARG
+        assert L.oem_comm_p2p_connect(h, C.addressof(blob)) == _lib.OEM_ERR_STATE        # nothing exported yet
+        assert L.oem_comm_p2p_export(h, 1000, C.addressof(blob)) in (_lib.OEM_ERR_HIP, _lib.OEM_ERR_NO_DEVICE, _lib.OEM_ERR_OOM)
+        assert L.oem_comm_set_option(h, 99, 0) == _lib.OEM_ERR_ARG
+        assert L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_MAX_BYTES, 0) == _lib.OEM_OK
+    finally:
+        L.oem_comm_destroy(h)
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under oarfish_amd/ may reference it."""
     pkg = os.path.join(ROOT, "oarfish_amd")
