@@ -96,10 +96,9 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__rest
             r.c[g] = 0u;
         }
     }
-    // the second element of the last pair of an odd-width slice belongs to the next read
-#pragma unroll
-    for (int k = 1; k < kBCh; k += 2)
-        if ((uint32_t)k >= width) r.w[k] = (WT)0;
+    // (The second element of the last pair of an odd-width slice belongs to the next read and must carry no
+    // weight: fold_slice_e masks it at the point of use.  Masking it HERE made the compiler wait for every pair
+    // right behind its loads -- four serialised round trips per register set in the kernel's prologue.)
 }
 
 // Alignments beyond the kBCh a register set holds are reloaded by both passes of the fold.  One alignment at a
@@ -134,7 +133,7 @@ __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const u
 // as the scatter is done with it (`next_*`).  Alignments beyond the register-resident ones are reloaded four at
 // a time by both passes.
 template <typename WT, bool kNT, bool kHasHi>
-__device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, const SliceRegsB<WT> &hi, uint32_t width, uint32_t mq,
+__device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> &hi, uint32_t width, uint32_t mq,
                                              uint32_t rl, uint32_t lane, const WT *__restrict__ wbase,
                                              const uint32_t *__restrict__ cbase, const double *theta_l, double *cnt_l,
                                              double *den_l, const uint32_t (&rot8)[kEB], uint32_t act_e, bool load_next,
@@ -142,13 +141,25 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, const SliceRegs
                                              uint32_t next_width)
 {
     constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
+    // Every use of the slice's registers stays below this point: without the pins the compiler hoists the
+    // f32 -> f64 conversions of the weights up to their loads and waits for each pair right behind them.
+#pragma unroll
+    for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(lo.w[k]));
+#pragma unroll
+    for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(lo.c[k]));
+    if (kHasHi) {
+#pragma unroll
+        for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(hi.w[k]));
+#pragma unroll
+        for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(hi.c[k]));
+    }
     double denom[kEB];
 #pragma unroll
     for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         const uint32_t off = ((k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu)) * kEB;
-        const double wk = (double)lo.w[k];
+        const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : (double)lo.w[k];
 #pragma unroll
         for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
         if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
@@ -157,7 +168,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, const SliceRegs
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             const uint32_t off = ((k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu)) * kEB;
-            const double wk = (double)hi.w[k];
+            const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : (double)hi.w[k];
 #pragma unroll
             for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
             if (k & 1) __builtin_amdgcn_sched_barrier(0);
@@ -334,16 +345,26 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     WT rw[kRemE];
     const uint32_t tid_base = td.problem * problem_size;
     const uint32_t *sd_t = sd + td.sd_begin - td.b_min; // slot of record i = sd_t[bucket of its transcript] + i
+    if (td.remote_cnt) { // wave-uniform
+        // branch-free: a thread without a record re-reads the tile's last one and gives it no weight, so the loads
+        // issue back to back (a load per branch is a round trip each)
+        const uint32_t last = td.remote_cnt - 1;
 #pragma unroll
-    for (int k = 0; k < kRemE; ++k) {
-        const uint32_t i = tx + k * kTileThreadsE;
-        rt[k] = 0; rw[k] = (WT)0; rrow[k] = 0; rslot[k] = 0;
-        if (i < td.remote_cnt) {
-            const uint32_t o = td.remote_begin + i;
+        for (int k = 0; k < kRemE; ++k) {
+            const uint32_t i = tx + k * kTileThreadsE;
+            const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
             ld_remote_b<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
             rw[k] = ld_stream_b<kNT>(&r_w[o]);
         }
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k)
+            if (tx + k * kTileThreadsE >= td.remote_cnt) rw[k] = (WT)0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
     }
+#pragma unroll
+    for (int k = 0; k < kRemE; ++k) rslot[k] = 0;
     {   // branch-free and back to back (a lookup per branch is a dependent round trip each); a thread without a
         // record reads the tile's first table word (or the table's slack word when the tile has no records)
         uint32_t sdv[kRemE];
@@ -379,11 +400,13 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote
         // denominators are never read and its queue entries stay at the zero the slot was loaded with
         // (launch_batch_reset_slot clears the slot's queue plane), so neither is touched.
-        uint32_t rmult[kRemE];
+        uint32_t rmult[kRemE]; // (loaded branch-free and back to back; a thread without a record discards its word)
 #pragma unroll
         for (int k = 0; k < kRemE; ++k)
-            rmult[k] = tx + k * kTileThreadsE < td.remote_cnt
-                           ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rrow[k]) * kB + eoff) : 0u;
+            rmult[k] = *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rrow[k]) * kB + eoff);
+#pragma unroll
+        for (int k = 0; k < kRemE; ++k)
+            if (tx + k * kTileThreadsE >= td.remote_cnt) rmult[k] = 0u;
         // remote alignments: x[b] = theta[t][b] * w; the epoch's four slots are one 32-byte piece
         double rx[kRemE][kEB];
 #pragma unroll
