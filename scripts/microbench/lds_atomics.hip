@@ -13,7 +13,9 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7f
 
 constexpr int kOps = 16; // addresses per lane, all issued per loop trip
 
-// MODE: 0 f64 atomic add, 1 u64 atomic add, 2 u32 atomic add, 3 b64 read, 4 b64 write, 5 f64 add with return
+// MODE: 0 f64 atomic add, 1 u64 atomic add, 2 u32 atomic add, 3 b64 read, 4 b64 write, 5 f64 add with return,
+//       6 u64 atomic add of an f64 value converted to 2^-44 fixed point in the loop (what a fixed-point count
+//         window would cost: conversion included), 7 f64 atomic add of the same varying value
 template <int MODE>
 __global__ __launch_bounds__(256) void k(double *out, uint32_t W, uint32_t iters, int pat)
 {
@@ -28,10 +30,12 @@ __global__ __launch_bounds__(256) void k(double *out, uint32_t W, uint32_t iters
         if (pat == 0) t = hash32(gid * 977u + j) % W;                                   // uniform random
         else if (pat == 1) t = (threadIdx.x + j * 67) % W;                              // conflict-free (consecutive lanes)
         else if (pat == 2) t = (hash32(j * 131u + (threadIdx.x >> 6)) % 16) * 4 + (threadIdx.x & 3); // 16 hot entries x 4 copies
-        else t = (hash32(j * 131u + (threadIdx.x >> 6)) % 16) * 4;                      // 16 hot entries, one copy (64 lanes, one address)
+        else if (pat == 3) t = (hash32(j * 131u + (threadIdx.x >> 6)) % 16) * 4;        // 16 hot entries, one copy (64 lanes, one address)
+        else t = (hash32(gid * 977u + (j >> 2)) % (W / 4)) * 4 + ((threadIdx.x + j) & 3); // [entry][4 slots], lanes rotate over the slots (k_em_tile_e)
         off[j] = t * 8;
     }
     double acc = 0;
+    double vv = 1.0 / (double)(1 + (gid & 15));
     char *base = reinterpret_cast<char *>(lds);
     for (uint32_t it = 0; it < iters; ++it) {
 #pragma unroll
@@ -42,8 +46,16 @@ __global__ __launch_bounds__(256) void k(double *out, uint32_t W, uint32_t iters
             else if (MODE == 2) __hip_atomic_fetch_add((uint32_t *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else if (MODE == 3) acc += *(volatile double *)p;
             else if (MODE == 4) *(volatile double *)p = (double)it;
-            else acc += __hip_atomic_fetch_add(p, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (MODE == 5) acc += __hip_atomic_fetch_add(p, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (MODE == 6) {
+                const double v = vv * (double)(j + 1);
+                __hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)(v * 0x1p44), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                const double v = vv * (double)(j + 1);
+                __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        vv += 0.125;
     }
     __syncthreads();
     double s = acc;
@@ -69,15 +81,17 @@ int main()
     const int blocks = 2048;
     double *out; CK(hipMalloc(&out, sizeof(double) * 256 * blocks));
     const uint32_t iters = 256, W = 2048;
-    const char *mn[] = {"f64 atomic add", "u64 atomic add", "u32 atomic add", "b64 read", "b64 write", "f64 add, returning"};
-    const char *pn[] = {"uniform random", "conflict-free", "16 hot x 4 copies", "16 hot, 1 copy"};
-    for (int pat = 0; pat < 4; ++pat)
-        for (int m = 0; m < 6; ++m) {
+    const char *mn[] = {"f64 atomic add", "u64 atomic add", "u32 atomic add", "b64 read", "b64 write", "f64 add, returning",
+                        "u64 add of cvt(f64)", "f64 add, varying"};
+    const char *pn[] = {"uniform random", "conflict-free", "16 hot x 4 copies", "16 hot, 1 copy", "[entry][4], rotated"};
+    for (int pat = 0; pat < 5; ++pat)
+        for (int m = 0; m < 8; ++m) {
             float ms = 0;
             switch (m) {
             case 0: ms = run<0>(out, W, iters, pat, blocks); break; case 1: ms = run<1>(out, W, iters, pat, blocks); break;
             case 2: ms = run<2>(out, W, iters, pat, blocks); break; case 3: ms = run<3>(out, W, iters, pat, blocks); break;
-            case 4: ms = run<4>(out, W, iters, pat, blocks); break; default: ms = run<5>(out, W, iters, pat, blocks); break;
+            case 4: ms = run<4>(out, W, iters, pat, blocks); break; case 5: ms = run<5>(out, W, iters, pat, blocks); break;
+            case 6: ms = run<6>(out, W, iters, pat, blocks); break; default: ms = run<7>(out, W, iters, pat, blocks); break;
             }
             const double n = (double)blocks * 256 * iters * kOps;
             printf("%-18s %-20s %8.3f ms  %9.1f Gop/s  (%.2f lanes/clk/CU @2.4GHz)\n", pn[pat], mn[m], ms, n / ms * 1e-6, n / (ms * 1e-3) / 256 / 2.4e9);
