@@ -127,7 +127,7 @@ struct DeviceTiled {
 // ---------------------------------------------------------------------------
 // Batched bootstrap: kBatch replicates ("slots") share each pass over the matrix
 // (oem_batch_kernels.hip).  Per-slot loop state, walked on the device:
-// RUNNING -> FINAL (small abundances zeroed, one more pass) -> FINISHED.
+// RUNNING -> FINAL (small abundances read as 0, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
 #ifndef OEM_KBATCH
 #define OEM_KBATCH 4
@@ -144,7 +144,7 @@ struct BatchState {
     uint32_t converged;
     uint32_t blocks_arrived; // only [0] is used
     uint32_t phase;
-    uint32_t zeroed;
+    uint32_t reserved0;
     uint32_t pad[2];
 };
 static_assert(sizeof(BatchState) == 48, "BatchState layout");

@@ -140,26 +140,12 @@ __global__ __launch_bounds__(kMT) void k_multi_decide(BatchState *st, uint32_t n
             if (s.niter >= p.max_iter) s.phase = kPhaseFinal;
         }
         s.rel_bits = 0ull;
-        s.zeroed = 0;
     }
     st[i] = s;
 }
 
-// em.rs:238-242 for the cells that just entered FINAL
-__global__ __launch_bounds__(kMT) void k_multi_zero_small(double *__restrict__ theta, BatchState *st, uint32_t T)
-{
-    const uint32_t p = blockIdx.y;
-    if (st[p].phase != kPhaseFinal || st[p].zeroed) return;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x) {
-        const size_t k = (size_t)p * T + i;
-        if (theta[k] < OEM_MIN_READ_THRESH) theta[k] = 0.0;
-    }
-}
-__global__ __launch_bounds__(kMT) void k_multi_mark_zeroed(BatchState *st, uint32_t n_problems)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_problems && st[i].phase == kPhaseFinal) st[i].zeroed = 1;
-}
+// (em.rs:238-242, the zeroing of small abundances before the final pass, is not a sweep here: k_em_tile reads
+// the abundances of a FINAL cell below the threshold as 0 on the way in.)
 
 } // namespace
 
@@ -178,14 +164,10 @@ int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const Mu
 {
     const DeviceTiled &t = s->tiled;
     const uint32_t T = mb.problem_size;
-    uint32_t gx = (T + kMT - 1) / kMT;
-    if (gx > 64) gx = 64;
     const uint32_t gp = (mb.n_problems + kMT - 1) / kMT;
     hipLaunchKernelGGL(k_multi_fold_reldiff, dim3(t.n_buckets), dim3(kFT), 0, s->stream, t.bucket_base, t.queue, t.q_dst,
                        theta, cnt, mb.out, mb.state, s->csr.n_txps, T);
     hipLaunchKernelGGL(k_multi_decide, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems, p, mb.n_unfinished);
-    hipLaunchKernelGGL(k_multi_zero_small, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, mb.state, T);
-    hipLaunchKernelGGL(k_multi_mark_zeroed, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }
@@ -200,8 +182,6 @@ int launch_multi_reldiff(oem_store *s, double *theta, double *cnt, const MultiBu
                        mb.state, T);
     hipLaunchKernelGGL(k_multi_decide, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems, p,
                        mb.n_unfinished);
-    hipLaunchKernelGGL(k_multi_zero_small, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, mb.state, T);
-    hipLaunchKernelGGL(k_multi_mark_zeroed, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

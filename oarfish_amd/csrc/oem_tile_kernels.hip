@@ -301,7 +301,12 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // (the descriptor is requested before the run's state is looked at: two scalar loads in flight, not a chain)
     const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
     if (state && state->done) return;
-    if (problems && problems[td.problem].phase == kPhaseFinished) return; // per-cell batch: this cell is done
+    // per-cell batch: a FINISHED cell takes no part; a cell on its FINAL pass reads abundances below the
+    // threshold as 0 (em.rs:238-242) -- done here, on the way in, instead of by a sweep over theta per pass
+    const uint32_t phase = problems ? problems[td.problem].phase : (uint32_t)kPhaseRunning;
+    if (phase == kPhaseFinished) return;
+    const bool fin = phase == kPhaseFinal; // wave-uniform
+    auto th = [&](double v) -> double { return (fin && v < OEM_MIN_READ_THRESH) ? 0.0 : v; };
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6); // SGPR: slice control flow is scalar
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
         }
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) rx[k] = theta[rt[k]] * (double)rw[k];
+        for (int k = 0; k < kRem; ++k) rx[k] = th(theta[rt[k]]) * (double)rw[k];
         // the slots are wanted last (phase B): a few words per tile, cache-resident.  Branch-free and back to
         // back -- a lookup per branch made the compiler wait for each one in turn, six dependent round trips
         // (a tile without remote records reads the table's slack word)
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint32_t i = tx + u * kTileThreads;
-        if (i < td.win_len) theta_l[i] = tw[u];
+        if (i < td.win_len) theta_l[i] = th(tw[u]);
     }
     for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t o = td.remote_begin + i;
         uint32_t t, row;
         ld_remote<kPacked, false>(r_a, r_row, o, tid_base, t, row);
-        const double x = theta[t] * (double)r_w[o];
+        const double x = th(theta[t]) * (double)r_w[o];
         queue[sd_t[t >> kBucketShift] + i] = x;
         lds_add_f64(&den_l[row], x);
     }
