@@ -322,8 +322,11 @@ int oem_comm_p2p_export(oem_comm *comm, uint64_t capacity, void *out_handle /* O
 int oem_comm_p2p_connect(oem_comm *comm, const void *all_handles /* n_ranks x OEM_P2P_HANDLE_BYTES */);
 
 /* Collective (every rank, same value).  OEM_COMM_OPT_P2P_MAX_BYTES: largest vector, in bytes, that takes
- * the peer-to-peer exchange when the communicator also has RCCL (default 4 MB; 0 = always RCCL). */
-typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1 } oem_comm_option;
+ * the peer-to-peer exchange when the communicator also has RCCL (default 4 MB; 0 = always RCCL).
+ * OEM_COMM_OPT_P2P_SHAPE: 0 (default) = by the number of ranks and the vector's size, 1 = one-shot (every rank reads every
+ * partial whole), 2 = two-phase (rank r sums slice r, then every rank reads the reduced slices from their
+ * owners: a quarter of the bytes per xGMI link at 8 ranks for one more flag round); oem_p2p.hip. */
+typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1, OEM_COMM_OPT_P2P_SHAPE = 2 } oem_comm_option;
 int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t value);
 
 /* Declare `store` to be rank-local row shard of a store with

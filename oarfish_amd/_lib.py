@@ -24,6 +24,7 @@ OEM_P2P_HANDLE_BYTES = 128
 OEM_OPT_BATCH_BOOTSTRAP = 1
 OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2
 OEM_COMM_OPT_P2P_MAX_BYTES = 1
+OEM_COMM_OPT_P2P_SHAPE = 2
 
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [

@@ -122,6 +122,7 @@ int p2p_connect(P2P *p, const void *all_blobs);
 int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state);
 int p2p_reldiff(P2P *p, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st);
 int p2p_check(P2P *p, hipStream_t st);
+void p2p_set_shape(P2P *p, int shape);
 
 // Vectors up to this size take the peer-to-peer exchange when it is connected (latency-bound: every
 // rank reads N - 1 partials over its own links at once); larger ones (the batched bootstrap's
@@ -336,6 +337,10 @@ extern "C" int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t val
     if (!c) return fail(OEM_ERR_ARG, "oem_comm_set_option: comm is NULL");
     switch (option) {
     case OEM_COMM_OPT_P2P_MAX_BYTES: c->p2p_max_bytes = (size_t)value; return OEM_OK;
+    case OEM_COMM_OPT_P2P_SHAPE:
+        if (value > 2) return fail(OEM_ERR_ARG, "oem_comm_set_option: peer-to-peer shape is 0 (by rank count), 1 (one-shot) or 2 (two-phase)");
+        p2p_set_shape(c->p2p, (int)value);
+        return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_comm_set_option: unknown option %u", option);
     }
     OEM_API_END("oem_comm_set_option")

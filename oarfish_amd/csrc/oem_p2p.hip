@@ -1,27 +1,41 @@
-// oem_p2p.hip -- one-shot peer-to-peer all-reduce of the count vector over the row shards of one node.
+// oem_p2p.hip -- peer-to-peer all-reduce of the count vector over the row shards of one node, without RCCL.
 //
 // The only exchange of the EM path is the sum of the n_txps partial counts per E/M pass (SURVEY.md
 // section 8e; in the reference the shared Vec<AtomicF64> of em.rs:338-341).  At 200 k transcripts that
 // is 1.6 MB: latency-bound, and a ring (RCCL's default, 2 (N-1) steps, each bound by ONE xGMI link) is
 // the wrong shape for it.  MI355X nodes are fully connected (7 links x ~153 GB/s per GPU), so here every
 // rank publishes its partial vector in a buffer its peers have mapped (hipIpc memory handles; the same
-// address space when the ranks are threads of one process) and then reads the N - 1 remote partials
-// directly, all links in parallel, summing them in rank order:
+// address space when the ranks are threads of one process) and the peers read it directly, all links in
+// parallel.  Two shapes, by the number of ranks:
 //
-//   k_p2p_publish   send -> own slot[parity]; system-scope fence; the last workgroup raises this
-//                   rank's flag in every peer's flag block (a peer spins on its OWN memory)
-//   k_p2p_reduce    waits for the N - 1 flags, recv[i] = sum over ranks r = 0..N-1 of slot_r[parity][i]
-//   k_p2p_reldiff   the same wait and sum fused into rel-diff / swap / clear / stopping rule
-//                   (em.rs:194-218): the reduced vector is never written and read back
+//   one-shot (N = 2, and short vectors): every rank reads the others' whole partials and adds in rank order.
+//     k_p2p_publish   send -> own slot[parity]; the last workgroup raises this rank's flag A in every
+//                     peer's flag block (a peer spins on its OWN memory)
+//     k_p2p_reduce    waits for the flags, recv[i] = sum over ranks r = 0..N-1 of slot_r[parity][i]
+//     k_p2p_reldiff   the same wait and sum fused into rel-diff / swap / clear / stopping rule
+//                     (em.rs:194-218): the reduced vector is never written and read back
+//   two-phase (N >= 3 and vectors of half a megabyte or more): one-shot pulls (N - 1) whole vectors through every rank's links -- 11 MB per rank and
+//     pass at N = 8 -- where a reduce-scatter + all-gather pulls 2 (N - 1) / N of ONE vector (2.8 MB), spread
+//     over the same N - 1 links: rank r sums slice r of all partials in rank order into its `red` buffer
+//     (k_p2p_reduce_slice, after the flags A; raises flag B at every peer), and the last kernel (k_p2p_gather /
+//     k_p2p_reldiff with kTwoPhase) waits for the flags B and reads every slice from its owner.  One more
+//     flag round and one more small kernel for a quarter of the bytes per link at N = 8.
+//   (oem_comm_set_option(OEM_COMM_OPT_P2P_SHAPE) forces either; bench.py times both next to RCCL on the node
+//   it runs on and keeps the fastest.)
 //
-// Every rank adds the partials in the same order, so the reduced vector is bit-identical on all ranks
-// and they take the identical stopping decision without a second exchange.  The slots are double-
-// buffered by the parity of a device-resident epoch counter: a rank overwrites slot[p] two exchanges
-// later, after its own previous exchange has seen every peer's flag for the exchange in between, which
-// a peer raises only after it has finished reading (stream order) -- no extra barrier.  The epoch lives
-// on the device and advances inside the kernels, so launches carry no per-call values and a chunk of
-// iterations can be replayed from a hipGraph.  Launches of a finished run (EmState::done) skip the
-// exchange on every rank alike, since the state they test is identical.
+// Every element is added in rank order, by every rank (one-shot) or by its one owner (two-phase), so the
+// reduced vector is bit-identical on all ranks and they take the identical stopping decision without a
+// second exchange.  The buffers are double-buffered by the parity of a device-resident epoch counter: a rank
+// overwrites slot[p] two exchanges later, after its own previous exchange has seen every peer's flag for the
+// exchange in between, which a peer raises only after it has finished reading (stream order) -- no extra
+// barrier; `red[p]` likewise (it is rewritten after the flags A of exchange e + 2, which a peer raises after
+// its last kernel of exchange e + 1, hence e, has read it).  The epoch lives on the device and advances
+// inside the kernels, so launches carry no per-call values and a chunk of iterations can be replayed from a
+// hipGraph.  Launches of a finished run (EmState::done) skip the exchange on every rank alike, since the
+// state they test is identical.
+//
+// Remote loads are round trips of microseconds: every kernel issues all the loads of a batch -- kP2PBatch
+// elements x all ranks -- before the first add (the sum itself stays in rank order).
 //
 // A spinning wait is bounded (wall clock): a peer that never arrives sets an error flag that the host
 // reports as OEM_ERR_STATE instead of hanging the GPU.
@@ -40,9 +54,10 @@ constexpr long long kP2PTimeoutTicks = 8ll * 100000000ll; // wall_clock64() runs
 
 // The region a rank shares with its peers (one allocation, one IPC handle).
 struct P2PShared {
-    unsigned long long flags[2][kP2PMaxRanks]; // [parity][source rank] = epoch of that rank's last publish
-    unsigned long long pad[512 - 2 * kP2PMaxRanks];
-    // double slot[2][capacity] follows
+    unsigned long long flags[2][kP2PMaxRanks];  // A: [parity][source rank] = epoch of that rank's last publish
+    unsigned long long flags_b[2][kP2PMaxRanks]; // B: ... of that rank's last reduced slice (two-phase)
+    unsigned long long pad[512 - 4 * kP2PMaxRanks];
+    // double slot[2][capacity] (partials), then double red[2][capacity] (reduced slices, indexed like the vector) follow
 };
 static_assert(sizeof(P2PShared) == 4096, "P2PShared header");
 
@@ -50,6 +65,12 @@ __host__ __device__ inline double *p2p_slot(P2PShared *s, uint64_t capacity, uin
 {
     return reinterpret_cast<double *>(reinterpret_cast<char *>(s) + sizeof(P2PShared)) + (size_t)parity * capacity;
 }
+__host__ __device__ inline double *p2p_red(P2PShared *s, uint64_t capacity, uint32_t parity)
+{
+    return p2p_slot(s, capacity, 2u + parity);
+}
+// slice of rank r of a vector of n elements: [p2p_slice_begin(r), p2p_slice_begin(r + 1))
+__host__ __device__ inline uint64_t p2p_slice_begin(uint64_t n, int r, int n_ranks) { return n * (uint64_t)r / (uint64_t)n_ranks; }
 
 // rank-local control block (device memory, never shared)
 struct P2PCtl {
@@ -57,7 +78,8 @@ struct P2PCtl {
     uint32_t arrived_pub;     // last-workgroup tickets
     uint32_t arrived_red;
     uint32_t error;           // 1: a peer's flag did not arrive in time
-    uint32_t pad[3];
+    uint32_t arrived_slice;
+    uint32_t pad[2];
     P2PShared *peer[kP2PMaxRanks]; // mapped regions, [rank] = own
 };
 
@@ -69,6 +91,7 @@ struct P2P {
     P2PCtl *h_ctl = nullptr; // pinned copy for error checks
     void *opened[kP2PMaxRanks] = {};  // hipIpcOpenMemHandle results to close
     bool connected = false;
+    int shape = 0; // OEM_COMM_OPT_P2P_SHAPE: 0 by the number of ranks, 1 one-shot, 2 two-phase
 };
 
 struct P2PBlob { // OEM_P2P_HANDLE_BYTES
@@ -133,13 +156,15 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restr
     }
 }
 
-// wait until every peer has published exchange `e` (their flags live in OUR region)
-__device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int rank, int n_ranks)
+// wait until every peer has raised its flag (A: published, B: slice reduced) for exchange `e`; the flags live
+// in OUR region
+__device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int rank, int n_ranks, bool flag_b = false)
 {
     // (once a wait has timed out the run is lost: later launches do not wait another 8 s each)
     if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank &&
         !__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        const unsigned long long *f = &ctl->peer[rank]->flags[e & 1][threadIdx.x];
+        P2PShared *self = ctl->peer[rank];
+        const unsigned long long *f = flag_b ? &self->flags_b[e & 1][threadIdx.x] : &self->flags[e & 1][threadIdx.x];
         const long long t0 = wall_clock64();
         while (sys_load_u64(f) < e) {
             __builtin_amdgcn_s_sleep(8);
@@ -152,29 +177,110 @@ __device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int 
     __syncthreads();
 }
 
-__device__ __forceinline__ double p2p_sum(const P2PCtl *ctl, uint64_t capacity, uint32_t parity, uint64_t i, int rank,
-                                          int n_ranks)
+constexpr int kP2PBatch = 4; // elements per thread whose loads are all in flight together
+
+// out[k] = sum over ranks, in rank order, of slot_r[parity][i[k]]: every load of the batch (kP2PBatch elements x
+// n_ranks, the own slot too: it was written through, a cached copy may predate that) is issued before the
+// first add -- a remote load is a round trip of microseconds, and rank after rank they would add up.
+__device__ __forceinline__ void p2p_sum_batch(const P2PCtl *ctl, uint64_t capacity, uint32_t parity, const uint64_t (&i)[kP2PBatch],
+                                              int n_ranks, double (&out)[kP2PBatch])
 {
-    double s = 0.0;
-    for (int r = 0; r < n_ranks; ++r) { // rank order: the same sum, bit for bit, on every rank
-        const double *slot = p2p_slot(ctl->peer[r], capacity, parity);
-        s += sys_load_f64(&slot[i]); // (own slot too: it was written through, a cached copy may predate that)
+#pragma unroll
+    for (int k = 0; k < kP2PBatch; ++k) out[k] = 0.0;
+    constexpr int kGroup = 8; // ranks whose loads are in flight together (kGroup * kP2PBatch * 2 VGPRs)
+    for (int r0 = 0; r0 < n_ranks; r0 += kGroup) {
+        double v[kGroup][kP2PBatch];
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g) {
+            if (r0 + g < n_ranks) { // uniform
+                const double *slot = p2p_slot(ctl->peer[r0 + g], capacity, parity);
+#pragma unroll
+                for (int k = 0; k < kP2PBatch; ++k) v[g][k] = sys_load_f64(&slot[i[k]]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g)
+            if (r0 + g < n_ranks) {
+#pragma unroll
+                for (int k = 0; k < kP2PBatch; ++k) out[k] += v[g][k]; // rank order: the same sum, bit for bit, wherever it is formed
+            }
     }
-    return s;
 }
 
+// two-phase: out[k] = the reduced element i[k], read from the rank that owns its slice
+__device__ __forceinline__ void p2p_gather_batch(const P2PCtl *ctl, uint64_t capacity, uint32_t parity, uint64_t count,
+                                                 const uint64_t (&i)[kP2PBatch], int n_ranks, double (&out)[kP2PBatch])
+{
+#pragma unroll
+    for (int k = 0; k < kP2PBatch; ++k) {
+        // owner of element i = the largest r with floor(count r / N) <= i  <=>  r < (i + 1) N / count
+        const int r = (int)(((i[k] + 1) * (uint64_t)n_ranks - 1) / count);
+        out[k] = sys_load_f64(&p2p_red(ctl->peer[r], capacity, parity)[i[k]]);
+    }
+}
+
+// two-phase, first half: after the flags A, this rank sums ITS slice of all partials into its `red` buffer
+// and raises flag B at every peer
+__global__ __launch_bounds__(kP2PBlock) void k_p2p_reduce_slice(P2PCtl *ctl, uint64_t capacity, uint64_t count, int rank,
+                                                                int n_ranks, const EmState *state)
+{
+    if (state && state->done) return;
+    const unsigned long long e = ctl->epoch + 1;
+    p2p_wait(ctl, e, rank, n_ranks);
+    const uint32_t parity = (uint32_t)(e & 1);
+    const uint64_t b = p2p_slice_begin(count, rank, n_ranks), end = p2p_slice_begin(count, rank + 1, n_ranks);
+    double *red = p2p_red(ctl->peer[rank], capacity, parity);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = b + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < end; i0 += kP2PBatch * stride) {
+        uint64_t idx[kP2PBatch];
+        double sum[kP2PBatch];
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k) idx[k] = i0 + k * stride < end ? i0 + k * stride : i0;
+        p2p_sum_batch(ctl, capacity, parity, idx, n_ranks, sum);
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k)
+            if (i0 + k * stride < end) sys_store_f64(&red[idx[k]], sum[k]);
+    }
+    stores_performed();
+    __syncthreads();
+    __shared__ bool is_last;
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&ctl->arrived_slice, 1u);
+        is_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank)
+            sys_store_u64(&ctl->peer[threadIdx.x]->flags_b[e & 1][rank], e);
+        if (threadIdx.x == 0) ctl->arrived_slice = 0u;
+    }
+}
+
+// recv = the reduced vector: summed here from all partials (one-shot) or gathered from the slice owners
+template <bool kTwoPhase>
 __global__ __launch_bounds__(kP2PBlock) void k_p2p_reduce(double *__restrict__ recv, P2PCtl *ctl, uint64_t capacity,
                                                           uint64_t count, int rank, int n_ranks, const EmState *state)
 {
     if (state && state->done) return;
     const unsigned long long e = ctl->epoch + 1;
-    p2p_wait(ctl, e, rank, n_ranks);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
-        recv[i] = p2p_sum(ctl, capacity, (uint32_t)(e & 1), i, rank, n_ranks);
+    p2p_wait(ctl, e, rank, n_ranks, kTwoPhase);
+    const uint32_t parity = (uint32_t)(e & 1);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < count; i0 += kP2PBatch * stride) {
+        uint64_t idx[kP2PBatch];
+        double sum[kP2PBatch];
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k) idx[k] = i0 + k * stride < count ? i0 + k * stride : i0;
+        if (kTwoPhase) p2p_gather_batch(ctl, capacity, parity, count, idx, n_ranks, sum);
+        else p2p_sum_batch(ctl, capacity, parity, idx, n_ranks, sum);
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k)
+            if (i0 + k * stride < count) recv[idx[k]] = sum[k];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t ticket = atomicAdd(&ctl->arrived_red, 1u);
-        if (ticket == gridDim.x - 1) { // every workgroup has read `epoch` (at its start) and its share of the slots
+        if (ticket == gridDim.x - 1) { // every workgroup has read `epoch` (at its start) and its share of the buffers
             ctl->arrived_red = 0u;
             __hip_atomic_store(&ctl->epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -182,21 +288,34 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_reduce(double *__restrict__ r
 }
 
 // The exchange fused into rel-diff / swap / clear / stopping rule (k_reldiff_swap_clear, oem_kernels.hip):
-// curr is this rank's partial (already published), the reduced value is summed from the slots.
-template <int kRB>
+// curr is this rank's partial (already published), the reduced value is summed from the slots (one-shot) or
+// read from the slice owners (two-phase).
+template <int kRB, bool kTwoPhase>
 __global__ __launch_bounds__(kRB) void k_p2p_reldiff(double *__restrict__ prev, double *__restrict__ curr, EmState *state,
                                                       EmParams p, P2PCtl *ctl, uint64_t capacity, int rank, int n_ranks)
 {
     if (state->done) return;
     const unsigned long long e = ctl->epoch + 1;
-    p2p_wait(ctl, e, rank, n_ranks);
+    p2p_wait(ctl, e, rank, n_ranks, kTwoPhase);
+    const uint32_t parity = (uint32_t)(e & 1);
     double rel = 0.0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < p.n_txps; i += gridDim.x * blockDim.x) {
-        const double cc = p2p_sum(ctl, capacity, (uint32_t)(e & 1), i, rank, n_ranks);
-        const double pc = prev[i];
-        if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
-        prev[i] = cc;                                                  // em.rs:204
-        curr[i] = 0.0;                                                 // em.rs:207
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, n = p.n_txps;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += kP2PBatch * stride) {
+        uint64_t idx[kP2PBatch];
+        double cc[kP2PBatch], pc[kP2PBatch];
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k) idx[k] = i0 + k * stride < n ? i0 + k * stride : i0;
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k) pc[k] = prev[idx[k]];
+        if (kTwoPhase) p2p_gather_batch(ctl, capacity, parity, n, idx, n_ranks, cc);
+        else p2p_sum_batch(ctl, capacity, parity, idx, n_ranks, cc);
+#pragma unroll
+        for (int k = 0; k < kP2PBatch; ++k)
+            if (i0 + k * stride < n) {
+                if (pc[k] > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc[k] - pc[k]) / pc[k]); // em.rs:195-199
+                prev[idx[k]] = cc[k];                                                    // em.rs:204
+                curr[idx[k]] = 0.0;                                                      // em.rs:207
+            }
     }
     for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
     __shared__ double smax[kRB / 64];
@@ -277,7 +396,7 @@ int p2p_export(P2P *p, uint64_t capacity, void *out_blob)
     if (!p || !out_blob || capacity == 0) return fail(OEM_ERR_ARG, "oem_comm_p2p_export: bad argument");
     if (p->self) return fail(OEM_ERR_STATE, "oem_comm_p2p_export: already exported");
     OEM_HIP(hipSetDevice(p->device));
-    const size_t bytes = sizeof(P2PShared) + 2 * capacity * sizeof(double);
+    const size_t bytes = sizeof(P2PShared) + 4 * capacity * sizeof(double); // partials and reduced slices, two parities each
     // Ordinary (cached) device memory: coherence with the peers comes from the system-scope fence before a
     // flag is raised, the system-scope acquire of the flags and system-scope loads of the peers' partials.
     // (Uncached memory was tried first: every access then goes to memory one lane at a time -- a 200 k-entry
@@ -358,32 +477,60 @@ int p2p_connect(P2P *p, const void *all_blobs)
     return OEM_OK;
 }
 
+// Two-phase costs one more flag round and one more small kernel (+6 us measured with 3-4 ranks on one device)
+// and saves (1 - 2 / N) of a vector per link: at ~50 GB/s per xGMI link that pays from about half a megabyte.
+bool p2p_two_phase(const P2P *p, uint64_t count)
+{
+    return p->shape == 2 || (p->shape == 0 && p->n_ranks >= 3 && count * sizeof(double) >= (512u << 10));
+}
+void p2p_set_shape(P2P *p, int shape) { if (p) p->shape = shape; }
+
 // recv = sum over ranks of send (in place allowed); counts beyond the slot capacity go in pieces
 int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state)
 {
     if (!p2p_ready(p)) return fail(OEM_ERR_STATE, "peer-to-peer exchange is not connected");
     for (size_t off = 0; off < count; off += p->capacity) {
         const uint64_t n = count - off < p->capacity ? count - off : p->capacity;
+        const bool two = p2p_two_phase(p, n);
         const int grid = grid_for_count(n, kP2PBlock, 128);
         hipLaunchKernelGGL(k_p2p_publish, dim3(grid), dim3(kP2PBlock), 0, st, send + off, p->ctl, p->capacity, n, p->rank,
                            p->n_ranks, state);
-        hipLaunchKernelGGL(k_p2p_reduce, dim3(grid), dim3(kP2PBlock), 0, st, recv + off, p->ctl, p->capacity, n, p->rank,
-                           p->n_ranks, state);
+        const int rgrid = grid_for_count((n + kP2PBatch - 1) / kP2PBatch, kP2PBlock, 128);
+        if (two) {
+            const uint64_t slice = n / (uint64_t)p->n_ranks + 1;
+            hipLaunchKernelGGL(k_p2p_reduce_slice, dim3(grid_for_count((slice + kP2PBatch - 1) / kP2PBatch, kP2PBlock, 64)),
+                               dim3(kP2PBlock), 0, st, p->ctl, p->capacity, n, p->rank, p->n_ranks, state);
+            hipLaunchKernelGGL(k_p2p_reduce<true>, dim3(rgrid), dim3(kP2PBlock), 0, st, recv + off, p->ctl, p->capacity, n,
+                               p->rank, p->n_ranks, state);
+        } else {
+            hipLaunchKernelGGL(k_p2p_reduce<false>, dim3(rgrid), dim3(kP2PBlock), 0, st, recv + off, p->ctl, p->capacity, n,
+                               p->rank, p->n_ranks, state);
+        }
     }
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }
 
-// publish this rank's partial `curr`, then rel-diff / swap / clear / stopping rule on the sum of the slots
+// publish this rank's partial `curr`, then rel-diff / swap / clear / stopping rule on the reduced vector
 int p2p_reldiff(P2P *p, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st)
 {
     if (!p2p_ready(p) || prm.n_txps > p->capacity) return fail(OEM_ERR_STATE, "peer-to-peer exchange: not connected / too small");
-    const int grid = grid_for_count(prm.n_txps, kP2PBlock, 128);
-    hipLaunchKernelGGL(k_p2p_publish, dim3(grid), dim3(kP2PBlock), 0, st, curr, p->ctl, p->capacity, (uint64_t)prm.n_txps,
-                       p->rank, p->n_ranks, state);
+    const uint64_t n = prm.n_txps;
+    const int grid = grid_for_count(n, kP2PBlock, 128);
+    hipLaunchKernelGGL(k_p2p_publish, dim3(grid), dim3(kP2PBlock), 0, st, curr, p->ctl, p->capacity, n, p->rank, p->n_ranks,
+                       state);
     constexpr int kRB = 1024;
-    hipLaunchKernelGGL(k_p2p_reldiff<kRB>, dim3(grid_for_count(prm.n_txps, kRB, 64)), dim3(kRB), 0, st, prev, curr, state, prm,
-                       p->ctl, p->capacity, p->rank, p->n_ranks);
+    const int rgrid = grid_for_count((n + kP2PBatch - 1) / kP2PBatch, kRB, 64);
+    if (p2p_two_phase(p, n)) {
+        const uint64_t slice = n / (uint64_t)p->n_ranks + 1;
+        hipLaunchKernelGGL(k_p2p_reduce_slice, dim3(grid_for_count((slice + kP2PBatch - 1) / kP2PBatch, kP2PBlock, 64)),
+                           dim3(kP2PBlock), 0, st, p->ctl, p->capacity, n, p->rank, p->n_ranks, state);
+        hipLaunchKernelGGL((k_p2p_reldiff<kRB, true>), dim3(rgrid), dim3(kRB), 0, st, prev, curr, state, prm, p->ctl,
+                           p->capacity, p->rank, p->n_ranks);
+    } else {
+        hipLaunchKernelGGL((k_p2p_reldiff<kRB, false>), dim3(rgrid), dim3(kRB), 0, st, prev, curr, state, prm, p->ctl,
+                           p->capacity, p->rank, p->n_ranks);
+    }
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

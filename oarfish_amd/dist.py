@@ -157,6 +157,11 @@ class Comm:
         """Collective: vectors above `n` bytes go to RCCL (0 = always RCCL)."""
         _lib.check(_lib.lib().oem_comm_set_option(self.handle, _lib.OEM_COMM_OPT_P2P_MAX_BYTES, int(n)))
 
+    def set_p2p_shape(self, shape: int):
+        """Collective: 0 = by the number of ranks and the vector size (two-phase from three ranks and 512 KB), 1 = one-shot,
+        2 = two-phase (reduce-scatter + all-gather over the mapped buffers)."""
+        _lib.check(_lib.lib().oem_comm_set_option(self.handle, _lib.OEM_COMM_OPT_P2P_SHAPE, int(shape)))
+
     def close(self):
         if self.handle is not None and self.handle.value:
             _lib.lib().oem_comm_destroy(self.handle)

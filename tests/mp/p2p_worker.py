@@ -7,7 +7,8 @@ and hipIpc memory handles allow.
 Every rank owns an nnz-balanced row shard, attaches a communicator WITHOUT RCCL and runs the collective
 oem_em_run (both gates), oem_m_step, the row-sharded batched bootstrap and the all-reduce timer.  Rank 0
 gathers everything and checks: identical iteration counts and BIT-identical reduced vectors on every rank,
-equal to the un-sharded store's run and to the oracle's.  usage: p2p_worker.py <out.json> [capacity-mode]"""
+equal to the un-sharded store's run and to the oracle's.
+usage: p2p_worker.py <out.json> [full|small (exchange buffers)] [0|1|2 (shape: by rank count, one-shot, two-phase)]"""
 import json
 import os
 import sys
@@ -24,6 +25,7 @@ from oarfish_amd.types import DeviceStore      # noqa: E402
 
 out_path = sys.argv[1]
 small_capacity = len(sys.argv) > 2 and sys.argv[2] == "small"   # exchange buffers smaller than the bootstrap's vector: pieces
+shape = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
@@ -36,6 +38,7 @@ try:
     with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, T, device=0) as d:
         comm = odist.create_comm(rank, world, 0, backend="p2p", p2p_capacity=T if small_capacity else 2 * T * 4)
         try:
+            comm.set_p2p_shape(shape)
             d.attach_comm(comm.handle, st.n_reads, sh.row_begin)
             theta = np.random.default_rng(3).uniform(0.0, 30.0, T)
             res["m_step"] = d.m_step(theta)
@@ -86,7 +89,7 @@ if rank == 0:
             with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as full:
                 full.time_em_iters(50)
                 one = full.time_em_iters(200) / 200 * 1e3
-            report = {"world": world, "niter": n, "n_txps": T, "allreduce_us": [r_["allreduce_us"] for r_ in rs],
+            report = {"world": world, "shape": shape, "niter": n, "n_txps": T, "allreduce_us": [r_["allreduce_us"] for r_ in rs],
                       "sharded_iteration_us": [r_["iteration_us"] for r_ in rs], "unsharded_iteration_us": one}
         except AssertionError as e:
             ok, report = False, {"assertion": repr(e)[:2000]}

@@ -82,7 +82,9 @@ def test_bench_two_ranks_on_one_device_over_p2p():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong"
     assert "row-shard x2" in d["config"]["parallelism"] and "ONE device" in d["config"]["parallelism"]
     ex = d["config"]["exchange"]
-    assert ex["p2p_connected"] and ex["allreduce_us"] > 0
+    assert ex["p2p_connected"] and ex["allreduce_us"] > 0 and ex["backend"].startswith("p2p")
+    for shape in ("p2p one-shot", "p2p two-phase"):   # both shapes reproduced each other and were timed
+        assert ex["candidates"][shape]["ok"] and ex["candidates"][shape]["iteration_us"] > 0
     assert d["bootstraps"]["n"] == 6 and d["bootstraps"]["value"] > 0 and "replica-parallel over 2" in d["bootstraps"]["mode"]
     assert d["cells"]["n_cells"] == 8 and d["cells"]["worst_mass_error"] < 1e-6 * d["cells"]["reads_per_cell"]
     for name in ("em", "em_par"):   # the sharded loop converges like the un-sharded one (tiny store: a handful of passes)

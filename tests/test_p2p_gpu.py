@@ -32,21 +32,22 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,mode", [(2, "full"), (3, "small"), (4, "full")])
-def test_row_sharded_loop_over_p2p_with_processes_sharing_one_gpu(world, mode, tmp_path):
+@pytest.mark.parametrize("world,mode,shape", [(2, "full", 0), (3, "small", 2), (4, "full", 2), (2, "small", 2), (3, "full", 1), (4, "small", 0)])
+def test_row_sharded_loop_over_p2p_with_processes_sharing_one_gpu(world, mode, shape, tmp_path):
+    """shape 0: what the library picks (one-shot for this store's short vectors); 1 / 2: one-shot / two-phase forced."""
     out = tmp_path / "p2p.json"
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "mp", "p2p_worker.py"), str(out), mode]
+           os.path.join(ROOT, "tests", "mp", "p2p_worker.py"), str(out), mode, str(shape)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     rep = json.load(open(out))
     assert rep["ok"] and rep["world"] == world, rep
     keep = os.path.join(ROOT, "gpurun_out")   # (scratch on the GPU box: the measured exchange time, for the notes)
     if os.path.isdir(keep):
-        with open(os.path.join(keep, f"p2p_processes_world{world}.json"), "w") as f:
+        with open(os.path.join(keep, f"p2p_processes_world{world}_shape{shape}.json"), "w") as f:
             json.dump(rep, f)
 
 
