@@ -8,7 +8,7 @@ from oarfish_amd import synth
 n_cells, rpc, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 cell_off, row_ptr, tid, p = synth.make_cells(n_cells, rpc, T, seed=3, threads=min(32, os.cpu_count() or 4))
 from oarfish_amd import _lib
-if os.environ.get("OEM_SERIAL_CELLS"):   # the cell-by-cell path is a knob of the test-only library
+if os.environ.get("OEM_SERIAL_CELLS") or os.environ.get("OEM_USE_TESTING_LIB") == "1":   # knobs live in the test-only library
     _lib.testing().__enter__()
 _lib.lib()  # load the library (and the process's HIP runtime) outside the timed region
 c2 = int(cell_off[2]); a2 = int(row_ptr[c2])
