@@ -756,8 +756,7 @@ int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
     // Window cap of the tiles: sparse stores (few reads per transcript, e.g. per-cell batches) fill
     // their tiles only with a wide window; dense ones are faster with the narrow one and four copies.
     uint32_t win_cap = opts ? opts->window_cap : 0u;
-    if (knob("OEM_WINCAP", 0) > 0) win_cap = (uint32_t)knob("OEM_WINCAP", 0); // testing build
-    if (win_cap != kWin && win_cap != kWinWide && win_cap != kWinMid) {
+    if (win_cap != kWin && win_cap != kWinWide) {
         // measured (scripts/wincap_ab.py): the wide cap wins on large sparse stores (2 M reads over 4 M
         // transcripts -10 %, a 625-cell batch -16 %), the narrow one on dense stores and on small ones,
         // which are latency-bound either way

@@ -40,7 +40,6 @@ namespace oem {
 constexpr uint32_t kTileRows = 1024;  // reads per tile (16 slices of 64)
 constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB of LDS); 8*kWin must fit 16 bits
 constexpr uint32_t kWinWide = 2048;   // window cap of sparse stores (few reads per transcript: per-cell batches)
-constexpr uint32_t kWinMid = 1024;    // experiment (test-only knob OEM_WINCAP): two count-window copies, 32 KiB of LDS
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
 constexpr uint32_t kBucket = 8192;    // transcripts per remote bucket (64 KiB of LDS)
 constexpr uint32_t kBucketShift = 13;

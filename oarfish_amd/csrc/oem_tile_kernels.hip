@@ -545,11 +545,7 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
 {
     const DeviceTiled &t = s->tiled;
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
-    if (t.win_cap > kWin && t.win_cap <= kWinMid)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 2, kNT, kWinMid, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
-                           t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size);
-    else if (t.win_cap > kWin)
+    if (t.win_cap > kWin)
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size);
