@@ -133,6 +133,7 @@ struct Comm {
     ncclComm_t comm = nullptr;
     P2P *p2p = nullptr;
     size_t p2p_max_bytes = kP2PMaxBytes; // OEM_COMM_OPT_P2P_MAX_BYTES (0: RCCL only)
+    int p2p_shape = 0;                   // OEM_COMM_OPT_P2P_SHAPE (kept here too: it may be set before the export)
     int rank = 0;
     int n_ranks = 1;
     int device = 0;
@@ -316,6 +317,7 @@ extern "C" int oem_comm_p2p_export(oem_comm *comm, uint64_t capacity, void *out_
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c || !out_handle || capacity == 0) return fail(OEM_ERR_ARG, "oem_comm_p2p_export: bad argument");
     if (!c->p2p) OEM_TRY(p2p_create(c->rank, c->n_ranks, c->device, &c->p2p));
+    p2p_set_shape(c->p2p, c->p2p_shape);
     return p2p_export(c->p2p, capacity, out_handle);
     OEM_API_END("oem_comm_p2p_export")
 }
@@ -339,7 +341,8 @@ extern "C" int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t val
     case OEM_COMM_OPT_P2P_MAX_BYTES: c->p2p_max_bytes = (size_t)value; return OEM_OK;
     case OEM_COMM_OPT_P2P_SHAPE:
         if (value > 2) return fail(OEM_ERR_ARG, "oem_comm_set_option: peer-to-peer shape is 0 (by rank count), 1 (one-shot) or 2 (two-phase)");
-        p2p_set_shape(c->p2p, (int)value);
+        c->p2p_shape = (int)value;
+        p2p_set_shape(c->p2p, c->p2p_shape);
         return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_comm_set_option: unknown option %u", option);
     }

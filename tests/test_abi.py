@@ -92,6 +92,9 @@ def test_p2p_communicator_without_a_device_fails_cleanly():
         assert L.oem_comm_p2p_export(h, 1000, C.addressof(blob)) in (_lib.OEM_ERR_HIP, _lib.OEM_ERR_NO_DEVICE, _lib.OEM_ERR_OOM)
         assert L.oem_comm_set_option(h, 99, 0) == _lib.OEM_ERR_ARG
         assert L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_MAX_BYTES, 0) == _lib.OEM_OK
+        for shape in (0, 1, 2):
+            assert L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_SHAPE, shape) == _lib.OEM_OK
+        assert L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_SHAPE, 3) == _lib.OEM_ERR_ARG
     finally:
         L.oem_comm_destroy(h)
 
