@@ -361,6 +361,10 @@ __global__ __launch_bounds__(kLThreads) void k_tile_fill(
 {
     __shared__ uint32_t woff[kTileSlices], coff[kTileSlices];
     __shared__ uint32_t rem_next;
+    // a read's transcripts are looked at (local alignments + 1) times by the selection below: short reads keep
+    // them in LDS (one private row per thread, odd stride), long ones go back to memory every time
+    constexpr uint32_t kCacheK = 16;
+    __shared__ uint32_t ct[kLThreads][kCacheK + 1];
     const TileDesc td = tiles[blockIdx.x];
     if (threadIdx.x == 0) {
         uint32_t a = td.w_base, c = td.c_base;
@@ -380,6 +384,10 @@ __global__ __launch_bounds__(kLThreads) void k_tile_fill(
         if (rl < td.n_rows) {
             const uint32_t r = perm[td.row_base + rl], anchor = key[r];
             const uint32_t j0 = row_ptr[r], j1 = row_ptr[r + 1];
+            const bool cached = j1 - j0 <= kCacheK;
+            if (cached)
+                for (uint32_t j = j0; j < j1; ++j) ct[threadIdx.x][j - j0] = tid[j];
+            auto tid_of = [&](uint32_t j) -> uint32_t { return cached ? ct[threadIdx.x][j - j0] : tid[j]; };
             // local alignments in the order (anchor first, then transcript, then position), by
             // repeated selection of the smallest key above the last one emitted
             unsigned long long last = 0; // keys are > 0
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kLThreads) void k_tile_fill(
                 unsigned long long best = ~0ull;
                 uint32_t best_j = 0;
                 for (uint32_t j = j0; j < j1; ++j) {
-                    const uint32_t t = tid[j];
+                    const uint32_t t = tid_of(j);
                     if (t - lo >= win) { if (first) ++n_rem; continue; }
                     const unsigned long long k = ((unsigned long long)(t == anchor ? 0u : t - lo + 1u) << 32) | (j - j0 + 1u);
                     if (k > last && k < best) { best = k; best_j = j; }
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(kLThreads) void k_tile_fill(
                 if (first && n_rem) { // reserve this read's remote records, then write them
                     uint32_t o = td.remote_begin + atomicAdd(&rem_next, n_rem);
                     for (uint32_t j = j0; j < j1; ++j) {
-                        const uint32_t t = tid[j];
+                        const uint32_t t = tid_of(j);
                         if (t - lo >= win) {
                             rem_key[o] = ((unsigned long long)t << 32) | j;
                             rem_row[o] = rl;
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(kLThreads) void k_tile_fill(
                 first = false;
                 if (best == ~0ull) break;
                 last = best;
-                const uint32_t code = (tid[best_j] - lo) * 8u; // LDS byte offset
+                const uint32_t code = (tid_of(best_j) - lo) * 8u; // LDS byte offset
                 w_out[wb + (size_t)nloc * 64] = w_in[best_j];
                 if (nloc & 1u) codes[cb + (size_t)(nloc >> 1) * 64] = pending | (code << 16);
                 else pending = code;
