@@ -49,22 +49,29 @@ __global__ __launch_bounds__(kLThreads) void k_anchor_keys(const uint32_t *__res
         atomicAdd(n_empty, 1u);
         return;
     }
+    // (the read's transcripts are compared all against all: short reads keep them in a private LDS row)
+    constexpr uint32_t kCacheK = 16;
+    __shared__ uint32_t ct[kLThreads][kCacheK + 1];
+    const bool cached = t - s <= kCacheK;
+    if (cached)
+        for (uint32_t j = s; j < t; ++j) ct[threadIdx.x][j - s] = tid[j];
+    auto tid_of = [&](uint32_t j) -> uint32_t { return cached ? ct[threadIdx.x][j - s] : tid[j]; };
     uint32_t best = s, best_n = 0;
     double best_w = -1.0;
     for (uint32_t j = s; j < t; ++j) {
-        const uint32_t tj = tid[j];
+        const uint32_t tj = tid_of(j);
         uint32_t n = 0;
         for (uint32_t i = s; i < t; ++i) {
-            const uint32_t ti = tid[i];
+            const uint32_t ti = tid_of(i);
             const uint32_t d = ti > tj ? ti - tj : tj - ti;
             n += d <= kMargin;
         }
         const double wj = (double)w[j];
-        if (n > best_n || (n == best_n && (wj > best_w || (wj == best_w && tj < tid[best])))) {
+        if (n > best_n || (n == best_n && (wj > best_w || (wj == best_w && tj < tid_of(best))))) {
             best = j; best_n = n; best_w = wj;
         }
     }
-    key[r] = tid[best];
+    key[r] = tid_of(best);
 }
 
 // ---- C ------------------------------------------------------------------------------------
