@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
-    const BatchState *__restrict__ problems, uint32_t problem_size)
+    const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles)
 {
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
@@ -299,7 +299,17 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 
     OEM_PROBE(0);
     // (the descriptor is requested before the run's state is looked at: two scalar loads in flight, not a chain)
-    const TileDesc td = tiles[blockIdx.x]; // one 64-byte scalar load
+    // Per-cell batch: the abundances of ALL cells together (300 MB for 625 cells) fit no cache, those of the cells
+    // one XCD is working on do (a cell's 60 k transcripts are 480 KB of its 4 MiB L2) -- if the XCD works on few
+    // cells at a time.  Block b runs on XCD b % 8 (observed placement: a matter of speed only), so block b takes
+    // tile (b % 8) * n_tiles / 8 + b / 8: every XCD streams through its own eighth of the cells in order, and the
+    // remote gathers hit its L2 instead of fetching a line from memory each (HBM reads of the kernel -45 %).
+    uint32_t tile_index = blockIdx.x;
+    if (problems) {
+        tile_index = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (tile_index >= n_tiles) return;
+    }
+    const TileDesc td = tiles[tile_index]; // one 64-byte scalar load
     if (state && state->done) return;
     // per-cell batch: a FINISHED cell takes no part; a cell on its FINAL pass reads abundances below the
     // threshold as 0 (em.rs:238-242) -- done here, on the way in, instead of by a sweep over theta per pass
@@ -545,14 +555,15 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
 {
     const DeviceTiled &t = s->tiled;
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
+    const uint32_t grid = problems ? (t.n_tiles + 7u) / 8u * 8u : t.n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size);
+                           row_w_perm, problems, t.problem_size, t.n_tiles);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked>), dim3(t.n_tiles), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size);
+                           row_w_perm, problems, t.problem_size, t.n_tiles);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)

@@ -2,12 +2,17 @@
 """Turn the separate FETCH_SIZE / WRITE_SIZE / calibration passes of scripts/collect_profiles.sh
 into profiles/<tag>_<wl>_hbm_traffic.json (HBM bytes per launch, per kernel; the file bench.py's
 roofline.traffic is read from).
-usage: hbm_traffic_json.py <collect dir> <workload> <out.json> <tag> [boot]
-  (boot: the kernels of the batched bootstrap pass, collected on scripts/boot_passes.py)"""
+usage: hbm_traffic_json.py <collect dir> <workload> <out.json> <tag> [boot|cells]
+  (boot: the kernels of the batched bootstrap pass, collected on scripts/boot_passes.py;
+   cells: the per-cell loop of scripts/cells_bench.py -- per-launch means AND totals over the loop's launches,
+   since the traffic of a pass falls as cells finish)"""
 import collections, csv, json, re, sys
 
 root, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
 KNOWN_KB = 1.5 * 1024 * 1024  # scripts/microbench/stream reads 1.5 GiB per launch
+
+
+COUNTS = {}
 
 
 def means(path):
@@ -17,19 +22,31 @@ def means(path):
             m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
             if m:
                 acc[m.group(1)].append(float(r["Counter_Value"]))
+    COUNTS[path] = {k: len(v) for k, v in acc.items()}
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
 cal = means(f"{root}/cal/cal_counter_collection.csv")["k_stream"]
 tag = [a for a in sys.argv[4:5]] or ["r01"]
 boot = len(sys.argv) > 5 and sys.argv[5] == "boot"
+cells = len(sys.argv) > 5 and sys.argv[5] == "cells"
 rd = means(f"{root}/pf/{tag[0]}_counter_collection.csv")
 wr = means(f"{root}/pw/{tag[0]}_counter_collection.csv")
 factor = KNOWN_KB / cal
 kern = {}
 names = ("k_em_tile_e", "k_remote_fold_b", "k_reldiff_b") if boot else ("k_em_tile", "k_remote_fold", "k_reldiff_swap_clear")
+if cells:
+    names = ("k_em_tile", "k_multi_fold_reldiff", "k_multi_decide")
 for k in names:
     kern[k] = {"read": rd[k] * 1024 * factor, "write": wr[k] * 1024}
+if cells:
+    n = COUNTS[f"{root}/pf/{tag[0]}_counter_collection.csv"]
+    doc = {"workload": wl, "command": "python scripts/cells_bench.py 625 50000 60000",
+           "fetch_factor": factor, "per_launch_mean_bytes": kern, "launches": {k: n[k] for k in names},
+           "loop_total_bytes": sum((kern[k]["read"] + kern[k]["write"]) * n[k] for k in names)}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc))
+    sys.exit(0)
 doc = {
     "workload": wl,
     "command": (f"python scripts/boot_passes.py {wl} 20  (4-slot batched passes, all slots running, one chain)" if boot else
