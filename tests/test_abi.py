@@ -148,3 +148,10 @@ def test_header_is_strict_c99(tmp_path):
                    'return OEM_ABI_VERSION == oem_abi_version() ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table says what each C entry point replaces in the reference: none may be missing."""
+    from oarfish_amd import build
+    doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    assert [s for s in build.header_symbols() if s not in doc] == []
