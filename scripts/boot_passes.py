@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few batched bootstrap passes on a C3-shaped store (profiling target)."""
+"""A few batched bootstrap passes on a C3-shaped store (profiling target).  usage: boot_passes.py [c3|c2] [n] [cov]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oarfish_amd import synth, _lib
@@ -9,8 +9,12 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ctx = _lib.testing() if os.environ.get("OEM_USE_TESTING_LIB") == "1" else None
 if ctx:
     ctx.__enter__()
-st = synth.make_config(wl)
-with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+cov = len(sys.argv) > 3 and sys.argv[3] == "cov"   # f64 weights (the coverage model): k_em_tile_e<.., double, ..>
+if cov:
+    st = synth.make_store(10_000_000, 200_000, 8.0, coverage=True, threads=min(32, os.cpu_count() or 8))
+else:
+    st = synth.make_config(wl)
+with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob if cov else None, st.n_txps) as d:
     ms, slots, nbytes = d.time_bootstrap_passes(n)
     print(f"batched pass: {ms:.4f} ms for {slots} replicates = {ms / slots * 1e3:.1f} us per replicate-pass; "
           f"{nbytes / ms / 1e6:.0f} GB/s algorithmic")
