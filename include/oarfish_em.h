@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-/* 2: oem_time_bootstrap_passes, oem_store_opts.layout_build (was reserved[0]), the peer-to-peer
- *    communicator entry points (oem_comm_p2p_*); version 1 callers keep working (additions only). */
+/* 2: oem_time_bootstrap_passes, oem_store_opts.layout_build and .weight_coding (were reserved words: zero = the
+ *    default, as before), the peer-to-peer communicator entry points (oem_comm_p2p_*), oem_store_info; version 1
+ *    callers keep working (additions only). */
 #define OEM_ABI_VERSION 2
 
 typedef enum {
@@ -76,7 +77,10 @@ typedef struct {
     uint32_t layout_build; /* 0 = build the tiled layout on the device (the host builder takes the stores the
                               device builder declines); 1 = always the host builder (oem_layout.cpp, the
                               specification the device builder is tested against) */
-    uint32_t reserved[4];
+    uint32_t weight_coding; /* 0 = a store with at most 256 distinct f32 weights (as_prob is exp of an integer score
+                              gap over a constant: tens to hundreds of values) keeps its local weights as one-byte
+                              indices into a table of them -- lossless; 1 = always the f32 stream (was reserved[0]) */
+    uint32_t reserved[3];
 } oem_store_opts;
 
 /* --------------------------------------------------------------------- */
@@ -123,6 +127,12 @@ int oem_store_dims(const oem_store *store, uint64_t *n_reads, uint64_t *nnz, uin
 /* Bytes of HBM the store occupies and the algorithmic bytes of one E/M pass
  * (nnz*(4+4|8) + (R+1)*4 + 2*T*8). */
 int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass);
+
+/* Facts about the resident layout.  OEM_INFO_WEIGHT_DICT_ENTRIES: entries of the weight table when the local
+ * weights are dictionary-coded (oem_store_opts.weight_coding), 0 when the store streams f32 / f64 weights;
+ * OEM_INFO_TILES, OEM_INFO_REMOTE_ALIGNMENTS: tiles of the layout and alignments outside their tile's window. */
+typedef enum { OEM_INFO_WEIGHT_DICT_ENTRIES = 1, OEM_INFO_TILES = 2, OEM_INFO_REMOTE_ALIGNMENTS = 3 } oem_store_info_key;
+int oem_store_info(const oem_store *store, uint32_t key, uint64_t *value);
 
 /* --------------------------------------------------------------------- */
 /* store builder: the step right before the EM (host side; only the *_device entry points use the GPU) */

@@ -25,6 +25,9 @@ OEM_OPT_BATCH_BOOTSTRAP = 1
 OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2
 OEM_COMM_OPT_P2P_MAX_BYTES = 1
 OEM_COMM_OPT_P2P_SHAPE = 2
+OEM_INFO_WEIGHT_DICT_ENTRIES = 1
+OEM_INFO_TILES = 2
+OEM_INFO_REMOTE_ALIGNMENTS = 3
 
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -84,7 +87,7 @@ REC_UNMAPPED, REC_REVERSE, REC_SUPPLEMENTARY, REC_HAS_SCORE = 1, 2, 4, 8
 
 class StoreOptsC(C.Structure):
     _fields_ = [("reorder_rows", C.c_uint32), ("problem_size", C.c_uint32), ("window_cap", C.c_uint32),
-                ("layout_build", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("layout_build", C.c_uint32), ("weight_coding", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 _lib = None       # the library the package calls into (the product, unless inside `testing()`)
@@ -113,6 +116,7 @@ def _load(path: str) -> C.CDLL:
     L.oem_store_destroy.restype = None
     L.oem_store_dims.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.oem_store_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.oem_store_info.argtypes = [vp, u32, C.POINTER(u64)]
     L.oem_store_set_option.argtypes = [vp, u32, u64]
     L.oem_builder_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
     L.oem_builder_destroy.argtypes = [vp]

@@ -29,7 +29,7 @@ TESTING_LIB_PATH = os.path.join(HERE, "liboarfish_em_testing.so")
 
 # sources of the product library
 SOURCES = ["oem_api.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip",
-           "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_layout_pack.hip", "oem_coverage_device.hip",
+           "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_layout_pack.hip", "oem_layout_dict.hip", "oem_coverage_device.hip",
            "oem_builder.cpp", "oem_comm.cpp", "oem_p2p.hip", "oem_knobs.cpp"]
 # the testing library swaps these for their -DOEM_TESTING build and adds the hooks
 TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip", "oem_batch_kernels.hip"]

@@ -567,6 +567,7 @@ void free_store(oem_store *s)
     hipFree(s->csr.w64);
     {
         oem::DeviceTiled &t = s->tiled;
+        hipFree(t.dict); hipFree(t.widx); hipFree(t.i_base);
         hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
         hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
         hipFree(t.r_slot); hipFree(t.r_pk); hipFree(t.sd); hipFree(t.q_dst); hipFree(t.bucket_base);
@@ -677,6 +678,10 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     // (the test-only library keeps the builders' streams when asked to: the layout tests hash them)
     OEM_TRY(pack_remote_records(s, opts ? opts->problem_size : 0u, knob("OEM_KEEP_UNPACKED", 0) != 0));
     tm.lap("slot table + packed records");
+    if (!opts || opts->weight_coding == 0) {
+        OEM_TRY(build_weight_dictionary(s)); // <= 256 distinct f32 weights: one byte per local alignment
+        tm.lap("weight dictionary");
+    }
     return OEM_OK;
 }
 
@@ -925,6 +930,19 @@ extern "C" int oem_store_set_option(oem_store *store, uint32_t option, uint64_t 
     default: return fail(OEM_ERR_ARG, "oem_store_set_option: unknown option %u", option);
     }
     OEM_API_END("oem_store_set_option")
+}
+
+extern "C" int oem_store_info(const oem_store *store, uint32_t key, uint64_t *value)
+{
+    OEM_API_BEGIN
+    if (!store || !value) return fail(OEM_ERR_ARG, "oem_store_info: NULL argument");
+    switch (key) {
+    case OEM_INFO_WEIGHT_DICT_ENTRIES: *value = store->tiled.present ? store->tiled.dict_n : 0u; return OEM_OK;
+    case OEM_INFO_TILES: *value = store->tiled.present ? store->tiled.n_tiles : 0u; return OEM_OK;
+    case OEM_INFO_REMOTE_ALIGNMENTS: *value = store->tiled.present ? store->tiled.n_remote : 0u; return OEM_OK;
+    default: return fail(OEM_ERR_ARG, "oem_store_info: unknown key %u", key);
+    }
+    OEM_API_END("oem_store_info")
 }
 
 extern "C" int oem_store_bytes(const oem_store *store, uint64_t *hbm_bytes, uint64_t *algorithmic_bytes_per_pass)

@@ -122,6 +122,11 @@ struct DeviceTiled {
     std::vector<uint32_t> h_bucket_base;
     double *queue = nullptr;      // n_remote f64: increments of the remote alignments, bucket-major
     uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
+    // dictionary-coded local weights (oem_layout_dict.hip), when the store has at most 256 distinct ones
+    uint32_t dict_n = 0;           // entries of the table (0: not coded, the kernels read w32)
+    float *dict = nullptr;         // 256 floats, ascending, [0] = 0.0
+    uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles
+    uint32_t *i_base = nullptr;    // n_tiles + 1: first index row of each tile
 };
 
 // ---------------------------------------------------------------------------
@@ -226,6 +231,7 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 // row_w is in the caller's read order; it is permuted into tile order first.
 // oem_layout_device.hip: the tiled layout built on the device from the resident CSR
 int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built);
+int build_weight_dictionary(oem_store *s); // oem_layout_dict.hip
 // oem_layout_pack.hip: slot table + packed remote records, after either builder
 int pack_remote_records(oem_store *s, uint32_t problem_size, bool keep_unpacked);
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,

@@ -75,9 +75,18 @@ __device__ __forceinline__ double *lds_at(double *base, uint32_t byte_off)
 // theta*w stays in registers between the two remote phases.
 template <typename WT, int kCh>
 struct SliceRegs {
-    WT w[kCh];
+    WT w[kCh];            // the weights themselves ...
+    uint32_t wi[kCh / 4]; // ... or (dictionary-coded stores, oem_layout_dict.hip) four one-byte table indices per word
     uint32_t c[kCh / 2];
 };
+// weight of entry k of a register set: kDict reads it from the table in LDS (index 0 = 0.0: padded entries and
+// entries beyond the slice's width need no masking)
+template <bool kDict, typename WT, int kCh>
+__device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const float *dict_l)
+{
+    if (kDict) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
+    return r.w[k];
+}
 
 // Issue every load of a slice before any use.  `wbase`/`cbase`/`width` are
 // wave-uniform (SGPRs), so the loads take the scalar-base + lane-offset form with
@@ -85,46 +94,66 @@ struct SliceRegs {
 // address arithmetic.  Pairs are loaded together; the second element of the last
 // pair of an odd-width slice is the next slice's first alignment (the arrays are
 // padded by one row) and is zeroed.
-template <typename WT, int kCh, bool kNT = false>
+template <typename WT, int kCh, bool kNT = false, bool kDict = false>
 __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, uint32_t lane,
-                                           uint32_t width)
+                                           uint32_t width, const uint32_t *__restrict__ ibase = nullptr)
 {
 #pragma unroll
     for (int g = 0; g < kCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
-            r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            if (kDict) {
+                if ((g & 1) == 0) r.wi[g >> 1] = ld_stream<kNT>(&ibase[(g >> 1) * 64 + lane]);
+            } else {
+                r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
+                r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            }
             r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
         } else {
-            r.w[2 * g] = (WT)0;
-            r.w[2 * g + 1] = (WT)0;
+            if (kDict) {
+                if ((g & 1) == 0) r.wi[g >> 1] = 0u;
+            } else {
+                r.w[2 * g] = (WT)0;
+                r.w[2 * g + 1] = (WT)0;
+            }
             r.c[g] = 0u;
         }
     }
 }
 
-template <typename WT, int kCh, int kCopies>
+template <typename WT, int kCh, int kCopies, bool kDict>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
                                            const double *theta_l, double *cnt_l, double *den_l,
-                                           const uint32_t *__restrict__ row_w_perm)
+                                           const uint32_t *__restrict__ row_w_perm,
+                                           const uint32_t *__restrict__ ibase, const float *dict_l)
 {
+    // weight of alignment j >= kCh of the lane's read (reload loops)
+    auto w_at = [&](uint32_t j) -> double {
+        if (kDict) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        return (double)wbase[j * 64 + lane];
+    };
     const uint32_t rl = s * 64 + lane;
     __builtin_amdgcn_sched_barrier(0);
     // Land every operand of this slice here (the loads of the NEXT slice stay in flight):
     // one counted s_waitcnt in front of the fold instead of a wait per alignment woven
     // through the LDS traffic.  Measured: 0.272 -> 0.237 ms per pass at C3.
+    if (kDict) {
 #pragma unroll
-    for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
+        for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(cur.wi[k]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
+    }
 #pragma unroll
     for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
     // the second element of the last pair of an odd-width slice belongs to the next row: it must
     // carry no weight.  Done once here, so the passes below need no per-alignment select.
     WT wz[kCh];
 #pragma unroll
-    for (int k = 0; k < kCh; ++k) wz[k] = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : cur.w[k];
+    for (int k = 0; k < kCh; ++k)
+        wz[k] = (!kDict && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(cur, k, dict_l);
     double x[kCh];
     double denom = den_l[rl];
 #pragma unroll
@@ -136,7 +165,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
-        denom += lds_ld(theta_l, off) * (double)wbase[j * 64 + lane];
+        denom += lds_ld(theta_l, off) * w_at(j);
     }
     double scale = 1.0;
     if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
@@ -173,7 +202,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
-        const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
+        const double v = lds_ld(theta_l, off) * w_at(j) * inv;
         if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
@@ -203,17 +232,28 @@ __device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, cons
 // loaded into the SECOND set with everything else at the top of the kernel (hidden behind the remote phases);
 // the fold runs over 16 register-resident alignments, hands the first set to the next slice's prefetch as
 // soon as its own scatter is done with it, and only reads with more than 16 local alignments reload.
-template <typename WT, int kCh, int kCopies, bool kNT>
+template <typename WT, int kCh, int kCopies, bool kNT, bool kDict>
 __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRegs<WT, kCh> &hi, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase,
                                            const TileDesc &td, const double *theta_l, double *cnt_l, double *den_l,
                                            const uint32_t *__restrict__ row_w_perm, bool prefetch_next,
-                                           const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width)
+                                           const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width,
+                                           const uint32_t *__restrict__ ibase, const uint32_t *__restrict__ next_i,
+                                           const float *dict_l)
 {
+    auto w_at = [&](uint32_t j) -> double {
+        if (kDict) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        return (double)wbase[j * 64 + lane];
+    };
     const uint32_t rl = s * 64 + lane;
     __builtin_amdgcn_sched_barrier(0);
+    if (kDict) {
 #pragma unroll
-    for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
+        for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
+    }
 #pragma unroll
     for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(lo.c[k]), "v"(hi.c[k]));
     // (load_slice zero-fills beyond the width; the second element of the last pair of an odd width belongs to
@@ -222,7 +262,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     double denom = den_l[rl];
 #pragma unroll
     for (int k = 0; k < kCh; ++k) {
-        const WT wk = ((k & 1) && (uint32_t)k >= width) ? (WT)0 : lo.w[k];
+        const WT wk = (!kDict && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(lo, k, dict_l);
         const uint32_t off = (k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu);
         x[k] = lds_ld(theta_l, off) * (double)wk;                            // em.rs:111
         denom += x[k];
@@ -230,7 +270,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     if (width > (uint32_t)kCh) { // wave-uniform
 #pragma unroll
         for (int k = 0; k < kCh; ++k) {
-            const WT wk = ((k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : hi.w[k];
+            const WT wk = (!kDict && (k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : slice_w<kDict>(hi, k, dict_l);
             const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
             denom += lds_ld(theta_l, off) * (double)wk;
         }
@@ -238,7 +278,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     for (uint32_t j = 2 * kCh; j < width; ++j) { // reads with more than 16 local alignments
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
-        denom += lds_ld(theta_l, off) * (double)wbase[j * 64 + lane];
+        denom += lds_ld(theta_l, off) * w_at(j);
     }
     double scale = 1.0;
     if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
@@ -265,13 +305,13 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
         }
     }
     // the first register set is done: the next slice's loads go out now, under the rest of this fold
-    if (prefetch_next) load_slice<WT, kCh, kNT>(lo, next_w, next_c, lane, next_width);
+    if (prefetch_next) load_slice<WT, kCh, kNT, kDict>(lo, next_w, next_c, lane, next_width, next_i);
     if (width > (uint32_t)kCh) {
 #pragma unroll
         for (int k = 0; k < kCh; ++k) {
             if ((uint32_t)(k + kCh) < width) { // uniform
                 const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
-                const double v = lds_ld(theta_l, off) * (double)hi.w[k] * inv;
+                const double v = lds_ld(theta_l, off) * (double)slice_w<kDict>(hi, k, dict_l) * inv;
                 if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
             }
         }
@@ -279,20 +319,22 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     for (uint32_t j = 2 * kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
-        const double v = lds_ld(theta_l, off) * (double)wbase[j * 64 + lane] * inv;
+        const double v = lds_ld(theta_l, off) * w_at(j) * inv;
         if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, bool kDict>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd,
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
-    const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles)
+    const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles,
+    const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict)
 {
+    __shared__ float dict_l[kDict ? 256 : 1]; // the distinct weights of a dictionary-coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
@@ -310,6 +352,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         if (tile_index >= n_tiles) return;
     }
     const TileDesc td = tiles[tile_index]; // one 64-byte scalar load
+    const uint32_t ib = kDict ? i_base[tile_index] : 0u; // (requested with it)
     if (state && state->done) return;
     // per-cell batch: a FINISHED cell takes no part; a cell on its FINAL pass reads abundances below the
     // threshold as 0 (em.rs:238-242) -- done here, on the way in, instead of by a sweep over theta per pass
@@ -329,9 +372,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     auto slice_of = [&](uint32_t q) -> uint32_t { return (q & 1u) ? (q + 1) * kWaves - 1 - wave : q * kWaves + wave; };
 
     // addresses of this wavefront's slices, from the widths alone (scalar prefix sums)
-    uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
+    uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave], ioff[kPerWave];
     {
-        uint32_t accw = td.w_base, accc = td.c_base;
+        uint32_t accw = td.w_base, accc = td.c_base, acci = ib;
 #pragma unroll
         for (uint32_t i = 0; i < kTileSlices; ++i) {
             const uint32_t wi = td.width[i];
@@ -339,12 +382,16 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             if (i == slice_of(q)) {
                 woff[q] = accw;
                 coff[q] = accc;
+                ioff[q] = acci;
                 wid[q] = wi;
             }
             accw += wi;
             accc += (wi + 1) >> 1;
+            acci += (wi + 3) >> 2;
         }
     }
+    // (a slice's index words, when the weights are dictionary-coded)
+    auto iptr = [&](uint32_t q) -> const uint32_t * { return kDict ? widx + (size_t)ioff[q] * 64 : nullptr; };
 
     OEM_PROBE(1); // descriptor in hand, slice addresses derived
     // ---- every long-latency load of the tile is issued here, before any use ---------
@@ -360,11 +407,13 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
     }
+    float dict_v = 0.0f;
+    if (kDict && tx < 256) dict_v = dict[tx]; // 1 KiB, L2-resident
     SliceRegs<WT, kCh> R[kSets];
-    load_slice<WT, kCh, kNT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+    load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
     // alignments 8..15 of the first slice, into the second set (see fold_first)
-    load_slice<WT, kCh, kNT>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
-                             wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u);
+    load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
+                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u, kDict ? iptr(0) + (kCh / 4) * 64 : nullptr);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -412,6 +461,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         if (i < td.win_len) theta_l[i] = th(tw[u]);
     }
+    if (kDict && tx < 256) dict_l[tx] = dict_v;
     for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
@@ -437,23 +487,23 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // ---- local alignments: one read per lane, all operands already in registers -----
     // slice 0: 16 register-resident alignments in both sets; it releases R[0] to slice 1's prefetch half way
     if (wave < td.n_slices)
-        fold_first<WT, kCh, kCopies, kNT>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
-                                          td, theta_l, cnt_l, den_l, row_w_perm, kPerWave > 1,
-                                          w + (size_t)woff[kPerWave > 1 ? 1 : 0] * 64, codes + (size_t)coff[kPerWave > 1 ? 1 : 0] * 64,
-                                          wid[kPerWave > 1 ? 1 : 0]);
+        fold_first<WT, kCh, kCopies, kNT, kDict>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
+                                                 td, theta_l, cnt_l, den_l, row_w_perm, kPerWave > 1,
+                                                 w + (size_t)woff[kPerWave > 1 ? 1 : 0] * 64, codes + (size_t)coff[kPerWave > 1 ? 1 : 0] * 64,
+                                                 wid[kPerWave > 1 ? 1 : 0], iptr(0), iptr(kPerWave > 1 ? 1 : 0), dict_l);
     else if (kPerWave > 1)
-        load_slice<WT, kCh, kNT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
+        load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1], iptr(1));
     OEM_PROBE(6);
     // slices 1..: slice q sits in R[(q - 1) % 2], slice q + 1 is prefetched into the other set
 #pragma unroll
     for (uint32_t q = 1; q < kPerWave; ++q) {
         const uint32_t s = slice_of(q);
         if (q + 1 < kPerWave)
-            load_slice<WT, kCh, kNT>(R[q % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
-                       wid[q + 1]);
+            load_slice<WT, kCh, kNT, kDict>(R[q % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
+                       wid[q + 1], iptr(q + 1 < kPerWave ? q + 1 : q));
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies>(R[(q - 1) % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
-                       theta_l, cnt_l, den_l, row_w_perm);
+            fold_slice<WT, kCh, kCopies, kDict>(R[(q - 1) % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+                       theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l);
         OEM_PROBE(6 + q); // wave 0's slice q folded (its operands had to land first)
     }
     __syncthreads();
@@ -549,7 +599,7 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 // remote alignments per thread in registers; 4 interleaved count-window copies for the narrow
 // window cap, one for the wide cap of sparse stores (40 KiB LDS; same-address atomics are rare
 // when few reads share a transcript).
-template <typename WT, bool kNT, bool kPacked>
+template <typename WT, bool kNT, bool kPacked, bool kDict>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
                         const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
 {
@@ -557,13 +607,13 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
     const uint32_t grid = problems ? (t.n_tiles + 7u) / 8u * 8u : t.n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles);
+                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles);
+                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)
@@ -591,17 +641,21 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
     const long nt_knob = knob("OEM_TILE_NT", -1); // testing build: 0 never, 1 always
     const bool nt = nt_knob < 0 ? stream_bytes > (192ull << 20) : nt_knob != 0;
-#define OEM_TILE(WT, NT, W, RW)                                                                             \
+#define OEM_TILE(WT, NT, W, RW, DICT)                                                                       \
     do {                                                                                                   \
-        if (t.packed) launch_tile<WT, NT, true>(s, W, RW, theta, cnt, state, row_w_perm, problems);                \
-        else launch_tile<WT, NT, false>(s, W, RW, theta, cnt, state, row_w_perm, problems);                        \
+        if (t.packed) launch_tile<WT, NT, true, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);          \
+        else launch_tile<WT, NT, false, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);                  \
     } while (0)
+    const bool dict = !f64w && t.dict_n > 0 && knob("OEM_NO_DICT", 0) == 0; // (knob: testing build, A/B)
     if (f64w) {
-        if (nt) OEM_TILE(double, true, t.w64, t.r_w64);
-        else OEM_TILE(double, false, t.w64, t.r_w64);
+        if (nt) OEM_TILE(double, true, t.w64, t.r_w64, false);
+        else OEM_TILE(double, false, t.w64, t.r_w64, false);
+    } else if (dict) {
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, true);
+        else OEM_TILE(float, false, t.w32, t.r_w32, true);
     } else {
-        if (nt) OEM_TILE(float, true, t.w32, t.r_w32);
-        else OEM_TILE(float, false, t.w32, t.r_w32);
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, false);
+        else OEM_TILE(float, false, t.w32, t.r_w32, false);
     }
 #undef OEM_TILE
     OEM_HIP(hipGetLastError());

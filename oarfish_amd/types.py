@@ -53,7 +53,7 @@ class DeviceStore:
     """RAII wrapper of an ``oem_store*`` (the matrix resident in HBM on one GPU)."""
 
     def __init__(self, row_ptr, tid, as_prob, cov_prob, n_txps: int, device: int = 0,
-                 reorder_rows: int = 0, window_cap: int = 0, layout_build: int = 0):
+                 reorder_rows: int = 0, window_cap: int = 0, layout_build: int = 0, weight_coding: int = 0):
         self._h = C.c_void_p()
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         tid = np.ascontiguousarray(tid, dtype=np.uint32)
@@ -69,6 +69,7 @@ class DeviceStore:
         opts.reorder_rows = reorder_rows
         opts.window_cap = window_cap      # 0 = chosen from the store; 512 / 2048 force it (oem_store_opts)
         opts.layout_build = layout_build  # 1 = host layout builder (the specification)
+        opts.weight_coding = weight_coding  # 1 = never dictionary-code the local weights
         L = _lib.lib()
         self._lib = L                     # the library that owns the handle
         self._check(L.oem_store_create(
@@ -194,6 +195,12 @@ class DeviceStore:
         ms = C.c_float(0)
         self._check(self._lib.oem_time_m_step(self.handle, n_launches, C.byref(ms)))
         return float(ms.value)
+
+    def info(self, key: int) -> int:
+        """oem_store_info: _lib.OEM_INFO_WEIGHT_DICT_ENTRIES / _TILES / _REMOTE_ALIGNMENTS."""
+        v = C.c_uint64(0)
+        self._check(self._lib.oem_store_info(self.handle, key, C.byref(v)))
+        return int(v.value)
 
     def time_em_iters(self, n_iters: int) -> float:
         ms = C.c_float(0)
