@@ -32,7 +32,7 @@ OEM_INFO_REMOTE_ALIGNMENTS = 3
 # every symbol include/oarfish_em.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "oem_abi_version", "oem_last_error", "oem_device_count",
-    "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_set_option",
+    "oem_store_create", "oem_store_destroy", "oem_store_dims", "oem_store_bytes", "oem_store_info", "oem_store_set_option",
     "oem_builder_create", "oem_builder_destroy", "oem_builder_add_group", "oem_builder_dims",
     "oem_builder_discard_table", "oem_builder_export", "oem_builder_coverage_probs",
     "oem_builder_coverage_probs_binomial", "oem_coverage_probs_device", "oem_builder_coverage_probs_device",

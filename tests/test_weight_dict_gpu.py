@@ -1,0 +1,106 @@
+"""GPU tests of the dictionary-coded local weights (oem_layout_dict.hip): as_prob = exp((score - best) / D) with
+integer scores (oarfish_types.rs:1100-1114) takes few distinct values; at most 256 of them are stored as one-byte
+indices into a table of the f32 values -- lossless -- and anything else keeps the f32 stream."""
+import numpy as np
+import pytest
+
+from oarfish_amd import _lib, synth
+from oarfish_amd.types import DeviceStore
+from oracle import c_oracle
+from tests.common import assert_counts_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights_with(n_distinct, size, rng):
+    vals = ((1.0 + np.arange(n_distinct)) / (n_distinct + 3.0)).astype(np.float32)
+    assert len(np.unique(vals)) == n_distinct
+    p = vals[rng.integers(0, n_distinct, size=size)]
+    p[:n_distinct] = vals            # every value occurs
+    return p
+
+
+def test_coded_and_plain_weights_give_the_same_answer_and_the_oracles():
+    st = synth.make_store(120_000, 9_000, seed=41)
+    T = st.n_txps
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    theta = np.random.default_rng(2).lognormal(0, 1.5, T)
+    want_m = c_oracle.m_step(o, theta)
+    want, wi = c_oracle.do_em(o, max_iter=300, conv_thresh=1e-3)
+    res = {}
+    for coding in (0, 1):
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T, weight_coding=coding) as d:
+            n = d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
+            assert (n > 0) == (coding == 0) and n <= 256
+            assert d.info(_lib.OEM_INFO_TILES) > 0 and 0 < d.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS) < st.nnz
+            m = d.m_step(theta)
+            cnt, info = d.em_run(None, 300, 1e-3, 50)
+            boots, _ = d.bootstrap(2, seed=4, max_iter=40)
+            res[coding] = (m, cnt, info.niter, boots)
+        assert_counts_close(m, want_m, st.n_reads, T, 1e-11, f"m_step, coding {coding}")
+        assert info.niter == wi.niter
+        assert_counts_close(cnt, want, st.n_reads, T, 1e-9, f"em, coding {coding}")
+    # the table holds the caller's f32 values bit for bit: the two layouts differ by summation order only
+    assert_counts_close(res[0][0], res[1][0], st.n_reads, T, 1e-12, "coded vs plain, one pass")
+    assert res[0][2] == res[1][2]
+    assert_counts_close(res[0][3][0], res[1][3][0], st.n_reads, T, 1e-9, "coded vs plain, bootstrap replicate")
+
+
+@pytest.mark.parametrize("n_distinct,coded", [(3, True), (255, True), (256, False), (5000, False)])
+def test_the_table_holds_at_most_256_values_including_the_zero_of_the_padding(n_distinct, coded):
+    st = synth.make_store(40_000, 3_000, seed=7)
+    rng = np.random.default_rng(n_distinct)
+    p = _weights_with(n_distinct, st.nnz, rng)
+    o = c_oracle.Store(st.row_ptr, st.tid, p, None, st.n_txps)
+    want, _ = c_oracle.do_em(o, max_iter=40, conv_thresh=0.0)
+    with DeviceStore(st.row_ptr, st.tid, p, None, st.n_txps) as d:
+        n = d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
+        assert (n > 0) == coded, n
+        if coded:
+            assert n == n_distinct + 1     # + the 0.0 of the SELL padding, index 0
+        got, _ = d.em_run(None, 40, 0.0, 50)
+    assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, f"{n_distinct} distinct weights")
+
+
+def test_continuous_and_coverage_weights_keep_their_streams():
+    st = synth.make_store(50_000, 4_000, seed=9, coverage=True)
+    p = np.random.default_rng(5).uniform(1e-3, 1.0, st.nnz).astype(np.float32)
+    for cov in (None, st.cov_prob):
+        o = c_oracle.Store(st.row_ptr, st.tid, p if cov is None else st.as_prob, cov, st.n_txps)
+        want, _ = c_oracle.do_em(o, max_iter=30, conv_thresh=0.0)
+        with DeviceStore(st.row_ptr, st.tid, p if cov is None else st.as_prob, cov, st.n_txps) as d:
+            assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0   # > 256 distinct f32 values / f64 products
+            got, _ = d.em_run(None, 30, 0.0, 50)
+        assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, "plain stream")
+
+
+def test_long_reads_take_the_reload_path_of_the_coded_weights():
+    """Reads with more than 16 alignments inside one window: the coded weights of alignments 16.. are reloaded
+    by both passes of the fold (four indices per word), rows and slices of every width up to 60."""
+    rng = np.random.default_rng(12)
+    R, T = 6_000, 900
+    k = rng.integers(1, 61, size=R)
+    k[:8] = 60
+    rp = np.zeros(R + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum(k)
+    base = rng.integers(0, T - 200, size=R)
+    tid = np.concatenate([np.sort(rng.choice(200, size=int(kk), replace=False)) + b for kk, b in zip(k, base)]).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 30, size=len(tid)) / 4.0).astype(np.float32)
+    o = c_oracle.Store(rp, tid, p, None, T)
+    want, wi = c_oracle.do_em(o, max_iter=60, conv_thresh=0.0)
+    W = rng.poisson(1.0, size=R).astype(np.uint32)
+    want_w, _ = c_oracle.do_em(o, max_iter=60, conv_thresh=0.0, row_w=W)
+    for coding in (0, 1):
+        with DeviceStore(rp, tid, p, None, T, weight_coding=coding) as d:
+            assert (d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) > 0) == (coding == 0)
+            got, _ = d.em_run(None, 60, 0.0, 50)
+            got_w, _ = d.bootstrap(1, row_w_all=W[None, :], max_iter=60, conv_thresh=0.0)
+        assert_counts_close(got, want, R, T, 1e-9, f"long reads, coding {coding}")
+        assert_counts_close(got_w[0], want_w, R, T, 1e-9, f"long reads resampled, coding {coding}")
+
+
+def test_unknown_info_key_is_an_argument_error():
+    st = synth.make_store(2_000, 300, seed=1)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
+        with pytest.raises(Exception):
+            d.info(99)
