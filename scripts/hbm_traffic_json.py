@@ -50,7 +50,7 @@ if cells:
 doc = {
     "workload": wl,
     "command": (f"python scripts/boot_passes.py {wl} 20  (4-slot batched passes, all slots running, one chain)" if boot else
-                f"python bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu-baseline --bootstraps 0 --cells 0"),
+                f"python bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu-baseline --no-f32-compare --bootstraps 0 --cells 0"),
     "fetch_calibration": {
         "kernel": "scripts/microbench/stream (rows of 64 lanes, 4/8/12/16 B per lane)",
         "known_KB_per_launch": KNOWN_KB, "FETCH_SIZE_KB": cal, "factor": factor,
