@@ -9,8 +9,8 @@
 // caller handed over -- lossless, no tolerance involved.  Measured at C3 (25 distinct weights): the pass
 // 0.199 -> 0.176 ms (profiles/r03_notes.md): the pass follows its bytes.
 //
-// Stores with more distinct weights (or f64 weights: the coverage model multiplies a second factor in) keep
-// the f32 stream; `oem_store_opts.weight_coding = 1` keeps it for any store.
+// Stores with more distinct weights, f64 weights (the coverage model multiplies a second factor in) or the wide
+// window cap (per-cell batches: see build_weight_dictionary) keep the f32 stream; `oem_store_opts.weight_coding = 1` keeps it for any store.
 //
 // Layout: slice s of a tile holds words(s) = (width[s] + 3) / 4 index words per lane,
 //     widx[(i_base[tile] + sum_{s' < s} words(s') + g) * 64 + lane]  = indices of alignments 4g .. 4g+3 of the lane's
@@ -142,6 +142,9 @@ int build_weight_dictionary(oem_store *s)
 {
     DeviceTiled &t = s->tiled;
     if (!t.present || t.n_tiles == 0 || s->csr.w_is_f64 || !t.w32) return OEM_OK;
+    // The wide-window instantiation of k_em_tile holds exactly four 40 KiB workgroups per CU: one more KiB for the
+    // table makes that three, and the per-cell loop it serves 5 % slower (measured: 647 -> 680 ms for 625 cells).
+    if (t.win_cap > kWin) return OEM_OK;
     hipStream_t st = s->stream;
     uint32_t *gtab = nullptr, *small = nullptr, *sizes = nullptr, *begins = nullptr;
     void *tmp = nullptr;
