@@ -67,6 +67,11 @@ __device__ __forceinline__ double *lds_at_b(double *base, uint32_t byte_off)
     return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
+// LDS byte offset of a 16-bit window code.  A store with at most 128 distinct weights carries a table index in the
+// code's spare bits (bits 0..2 and 12..15: oem_layout_dict.hip, read by k_em_tile); this kernel reads the f32 weight
+// stream and only has to look past them (the batched kernel serves narrow-window stores: offsets are bits 3..11).
+__device__ __forceinline__ uint32_t code_off_b(uint32_t half) { return half & 0x0ff8u; }
+
 template <typename WT>
 struct SliceRegsB {
     WT w[kBCh];
@@ -120,10 +125,10 @@ __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const u
 #pragma unroll
     for (int m = 0; m < 4; ++m)
         if (i0 + m >= width) wv[m] = (WT)0;
-    off[0] = (c0 & 0xffffu) * kEB;
-    off[1] = (c0 >> 16) * kEB;
-    off[2] = (c1 & 0xffffu) * kEB;
-    off[3] = (c1 >> 16) * kEB;
+    off[0] = code_off_b(c0) * kEB;
+    off[1] = code_off_b(c0 >> 16) * kEB;
+    off[2] = code_off_b(c1) * kEB;
+    off[3] = code_off_b(c1 >> 16) * kEB;
 }
 
 // The fold of one slice for the four slots of an epoch: denominators (pass 1), c_ib / denom_ib, scatter (pass 2,
@@ -158,7 +163,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
     for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
-        const uint32_t off = ((k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu)) * kEB;
+        const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
         const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : (double)lo.w[k];
 #pragma unroll
         for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
@@ -167,7 +172,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
     if (kHasHi && width > (uint32_t)kBCh) { // wave-uniform
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
-            const uint32_t off = ((k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu)) * kEB;
+            const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
             const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : (double)hi.w[k];
 #pragma unroll
             for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
@@ -200,7 +205,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         if ((uint32_t)k < width) { // wave-uniform
-            const uint32_t off = ((k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu)) * kEB;
+            const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
             const double wk = (double)lo.w[k];
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
@@ -216,7 +221,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             if ((uint32_t)(k + kBCh) < width) { // wave-uniform
-                const uint32_t off = ((k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu)) * kEB;
+                const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
                 const double wk = (double)hi.w[k];
 #pragma unroll
                 for (int j = 0; j < kEB; ++j) {

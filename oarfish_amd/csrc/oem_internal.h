@@ -124,6 +124,7 @@ struct DeviceTiled {
     uint32_t *row_w_perm = nullptr; // bootstrap multiplicities in permuted read order
     // dictionary-coded local weights (oem_layout_dict.hip), when the store has at most 256 distinct ones
     uint32_t dict_n = 0;           // entries of the table (0: not coded, the kernels read w32)
+    bool dict_fused = false;       // <= 128 entries: the index sits in the spare bits of the window codes, no widx
     float *dict = nullptr;         // 256 floats, ascending, [0] = 0.0
     uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles
     uint32_t *i_base = nullptr;    // n_tiles + 1: first index row of each tile

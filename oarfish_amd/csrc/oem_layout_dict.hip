@@ -3,10 +3,12 @@
 // The weight of an alignment is as_prob = exp((score - best score of the read) / D) in f32
 // (oarfish_types.rs:1100-1114): alignment scores are integers, so a store holds as many distinct weights as it
 // holds distinct score gaps -- tens to a few hundred, not 80 M.  When there are at most 256 of them the local
-// weights are stored as BYTES: an index into a table of the distinct f32 values, four indices per u32 in the
-// tiles' SELL layout.  A local alignment then costs 1 + 2 bytes of the E/M pass's stream instead of 4 + 2, the
-// table sits in 1 KiB of LDS per workgroup, and the value the kernel multiplies with is bit for bit the f32 the
-// caller handed over -- lossless, no tolerance involved.  Measured at C3 (25 distinct weights): the pass
+// weights are stored as an index into a table of the distinct f32 values: with up to 128 values FUSED into the
+// spare bits of the alignment's 16-bit window code (bits 0..2 and 12..15: a code is 8 * (transcript - lo) < 4096)
+// -- a local alignment is then its two code bytes and nothing else -- with 129..256 as BYTES, four indices per u32
+// in the tiles' SELL layout (1 + 2 bytes per local alignment).  The f32 stream costs 4 + 2.  The table sits in
+// 1 KiB of LDS per workgroup, and the value the kernel multiplies with is bit for bit the f32 the caller handed
+// over -- lossless, no tolerance involved.  Measured at C3 (25 distinct weights): the pass
 // 0.199 -> 0.176 ms (profiles/r03_notes.md): the pass follows its bytes.
 //
 // Stores with more distinct weights, f64 weights (the coverage model multiplies a second factor in) or the wide
@@ -134,6 +136,44 @@ __global__ __launch_bounds__(kDT) void k_dict_encode(const TileDesc *__restrict_
     }
 }
 
+// <= 128 distinct weights: the index goes into the spare bits of the alignment's own window code (bits 0..2 and
+// 12..15 of its 16-bit half; the code is 8 * (transcript - lo) < 4096), no index stream
+__global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ tiles, const float *__restrict__ w,
+                                                   const float *__restrict__ dict, uint32_t n_dict,
+                                                   uint32_t *__restrict__ codes, uint32_t *bad)
+{
+    __shared__ uint32_t keys[256];
+    const TileDesc td = tiles[blockIdx.x];
+    keys[threadIdx.x] = threadIdx.x < n_dict ? __float_as_uint(dict[threadIdx.x]) : 0x7f800000u;
+    __syncthreads();
+    uint32_t woff = td.w_base, coff = td.c_base;
+    for (uint32_t s = 0; s < kTileSlices; ++s) {
+        const uint32_t width = td.width[s], pairs = (width + 1u) >> 1;
+        for (uint32_t e = threadIdx.x; e < pairs * 64; e += kDT) {
+            const uint32_t g = e >> 6, lane = e & 63u;
+            uint32_t word = codes[(size_t)(coff + g) * 64 + lane];
+            for (uint32_t m = 0; m < 2; ++m) {
+                const uint32_t j = 2 * g + m;
+                if (j >= width) break;
+                const uint32_t key = __float_as_uint(w[(size_t)(woff + j) * 64 + lane]);
+                uint32_t a = 0, b = n_dict;
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (keys[mid] < key) a = mid + 1;
+                    else b = mid;
+                }
+                if (a >= n_dict || keys[a] != key || a > 127u) { *bad = 1u; a = 0; }
+                const uint32_t half = (word >> (16 * m)) & 0xffffu;
+                if (half & 0xf007u) *bad = 1u; // (a code of the narrow window has these bits clear)
+                word |= ((a & 7u) | ((a & 0x78u) << 9)) << (16 * m);
+            }
+            codes[(size_t)(coff + g) * 64 + lane] = word;
+        }
+        woff += width;
+        coff += pairs;
+    }
+}
+
 } // namespace
 
 // s->tiled holds a complete layout with f32 weights; on return it also holds the coded weights when the store
@@ -184,6 +224,18 @@ int build_weight_dictionary(oem_store *s)
         for (size_t i = 0; i < keys.size(); ++i) std::memcpy(&dict[i], &keys[i], sizeof(float));
         OEM_HIP(hipMalloc((void **)&t.dict, sizeof(float) * 256));
         OEM_HIP(hipMemcpyAsync(t.dict, dict.data(), sizeof(float) * 256, hipMemcpyHostToDevice, st));
+        if (keys.size() <= 128 && knob("OEM_DICT_NO_FUSE", 0) == 0) { // (knob: testing build, reaches the byte-stream coding)
+            // the index fits the spare bits of the window codes: no stream of its own
+            hipLaunchKernelGGL(k_dict_fuse, dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict, (uint32_t)keys.size(),
+                               t.codes, small + 2);
+            OEM_HIP(hipGetLastError());
+            OEM_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
+            OEM_HIP(hipStreamSynchronize(st));
+            if (h_small[2]) return fail(OEM_ERR_STATE, "weight dictionary: a window code or a weight did not fit the fused form");
+            t.dict_fused = true;
+            t.dict_n = (uint32_t)keys.size();
+            return OEM_OK;
+        }
         // per-tile bases of the index words
         OEM_HIP(hipMalloc((void **)&sizes, sizeof(uint32_t) * ((size_t)t.n_tiles + 1)));
         OEM_HIP(hipMalloc((void **)&begins, sizeof(uint32_t) * ((size_t)t.n_tiles + 1)));

@@ -79,12 +79,22 @@ struct SliceRegs {
     uint32_t wi[kCh / 4]; // ... or (dictionary-coded stores, oem_layout_dict.hip) four one-byte table indices per word
     uint32_t c[kCh / 2];
 };
-// weight of entry k of a register set: kDict reads it from the table in LDS (index 0 = 0.0: padded entries and
-// entries beyond the slice's width need no masking)
-template <bool kDict, typename WT, int kCh>
+// Weight coding of a store (oem_layout_dict.hip): 0 the f32 / f64 stream; 1 one-byte table indices in their own
+// stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
+// (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
+// no weight stream at all, a local alignment is its two code bytes.
+constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2;
+__device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
+template <int kDict>
+__device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
+__device__ __forceinline__ uint32_t code_widx(uint32_t half) { return (half & 7u) | ((half >> 9) & 0x78u); }
+// weight of entry k of a register set: coded stores read it from the table in LDS (index 0 = 0.0: padded entries
+// and entries beyond the slice's width need no masking)
+template <int kDict, typename WT, int kCh>
 __device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const float *dict_l)
 {
-    if (kDict) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
+    if (kDict == kWBytes) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
+    if (kDict == kWFused) return (WT)dict_l[code_widx(code_half(r.c[k >> 1], k & 1))];
     return r.w[k];
 }
 
@@ -94,7 +104,7 @@ __device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const 
 // address arithmetic.  Pairs are loaded together; the second element of the last
 // pair of an odd-width slice is the next slice's first alignment (the arrays are
 // padded by one row) and is zeroed.
-template <typename WT, int kCh, bool kNT = false, bool kDict = false>
+template <typename WT, int kCh, bool kNT = false, int kDict = kWPlain>
 __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, uint32_t lane,
                                            uint32_t width, const uint32_t *__restrict__ ibase = nullptr)
@@ -102,17 +112,17 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
 #pragma unroll
     for (int g = 0; g < kCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            if (kDict) {
+            if (kDict == kWBytes) {
                 if ((g & 1) == 0) r.wi[g >> 1] = ld_stream<kNT>(&ibase[(g >> 1) * 64 + lane]);
-            } else {
+            } else if (kDict == kWPlain) {
                 r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
                 r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
             }
             r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
         } else {
-            if (kDict) {
+            if (kDict == kWBytes) {
                 if ((g & 1) == 0) r.wi[g >> 1] = 0u;
-            } else {
+            } else if (kDict == kWPlain) {
                 r.w[2 * g] = (WT)0;
                 r.w[2 * g + 1] = (WT)0;
             }
@@ -121,7 +131,7 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
     }
 }
 
-template <typename WT, int kCh, int kCopies, bool kDict>
+template <typename WT, int kCh, int kCopies, int kDict>
 __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase,
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
@@ -131,7 +141,8 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 {
     // weight of alignment j >= kCh of the lane's read (reload loops)
     auto w_at = [&](uint32_t j) -> double {
-        if (kDict) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
         return (double)wbase[j * 64 + lane];
     };
     const uint32_t rl = s * 64 + lane;
@@ -139,10 +150,10 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     // Land every operand of this slice here (the loads of the NEXT slice stay in flight):
     // one counted s_waitcnt in front of the fold instead of a wait per alignment woven
     // through the LDS traffic.  Measured: 0.272 -> 0.237 ms per pass at C3.
-    if (kDict) {
+    if (kDict == kWBytes) {
 #pragma unroll
         for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(cur.wi[k]));
-    } else {
+    } else if (kDict == kWPlain) {
 #pragma unroll
         for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
     }
@@ -153,18 +164,18 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     WT wz[kCh];
 #pragma unroll
     for (int k = 0; k < kCh; ++k)
-        wz[k] = (!kDict && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(cur, k, dict_l);
+        wz[k] = (kDict == kWPlain && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(cur, k, dict_l);
     double x[kCh];
     double denom = den_l[rl];
 #pragma unroll
     for (int k = 0; k < kCh; ++k) {
-        const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
+        const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
         x[k] = lds_ld(theta_l, off) * (double)wz[k];                       // em.rs:111
         denom += x[k];
     }
     for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         denom += lds_ld(theta_l, off) * w_at(j);
     }
     double scale = 1.0;
@@ -181,7 +192,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     // share it, and 64 same-address LDS atomics would serialise: reduce across the
     // wavefront and let one lane add.
     {
-        const uint32_t off0 = cur.c[0] & 0xffffu;
+        const uint32_t off0 = code_off<kDict>(code_half(cur.c[0], 0));
         const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
@@ -194,14 +205,14 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 #pragma unroll
     for (int k = 1; k < kCh; ++k) {
         if ((uint32_t)k < width) { // uniform
-            const uint32_t off = (k & 1) ? (cur.c[k >> 1] >> 16) : (cur.c[k >> 1] & 0xffffu);
+            const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
             const double v = x[k] * inv;
             if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
         if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
@@ -232,7 +243,7 @@ __device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, cons
 // loaded into the SECOND set with everything else at the top of the kernel (hidden behind the remote phases);
 // the fold runs over 16 register-resident alignments, hands the first set to the next slice's prefetch as
 // soon as its own scatter is done with it, and only reads with more than 16 local alignments reload.
-template <typename WT, int kCh, int kCopies, bool kNT, bool kDict>
+template <typename WT, int kCh, int kCopies, bool kNT, int kDict>
 __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRegs<WT, kCh> &hi, uint32_t width, uint32_t s,
                                            uint32_t lane, const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase,
                                            const TileDesc &td, const double *theta_l, double *cnt_l, double *den_l,
@@ -242,15 +253,16 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
                                            const float *dict_l)
 {
     auto w_at = [&](uint32_t j) -> double {
-        if (kDict) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
         return (double)wbase[j * 64 + lane];
     };
     const uint32_t rl = s * 64 + lane;
     __builtin_amdgcn_sched_barrier(0);
-    if (kDict) {
+    if (kDict == kWBytes) {
 #pragma unroll
         for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
-    } else {
+    } else if (kDict == kWPlain) {
 #pragma unroll
         for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
     }
@@ -262,22 +274,22 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     double denom = den_l[rl];
 #pragma unroll
     for (int k = 0; k < kCh; ++k) {
-        const WT wk = (!kDict && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(lo, k, dict_l);
-        const uint32_t off = (k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu);
+        const WT wk = (kDict == kWPlain && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(lo, k, dict_l);
+        const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
         x[k] = lds_ld(theta_l, off) * (double)wk;                            // em.rs:111
         denom += x[k];
     }
     if (width > (uint32_t)kCh) { // wave-uniform
 #pragma unroll
         for (int k = 0; k < kCh; ++k) {
-            const WT wk = (!kDict && (k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : slice_w<kDict>(hi, k, dict_l);
-            const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
+            const WT wk = (kDict == kWPlain && (k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : slice_w<kDict>(hi, k, dict_l);
+            const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
             denom += lds_ld(theta_l, off) * (double)wk;
         }
     }
     for (uint32_t j = 2 * kCh; j < width; ++j) { // reads with more than 16 local alignments
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         denom += lds_ld(theta_l, off) * w_at(j);
     }
     double scale = 1.0;
@@ -286,7 +298,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     den_l[rl] = inv;
     const uint32_t copy_off = (lane % kCopies) * 8u;
     {
-        const uint32_t off0 = lo.c[0] & 0xffffu;
+        const uint32_t off0 = code_off<kDict>(code_half(lo.c[0], 0));
         const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
@@ -299,7 +311,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
 #pragma unroll
     for (int k = 1; k < kCh; ++k) {
         if ((uint32_t)k < width) { // uniform
-            const uint32_t off = (k & 1) ? (lo.c[k >> 1] >> 16) : (lo.c[k >> 1] & 0xffffu);
+            const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
             const double v = x[k] * inv;
             if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
@@ -310,7 +322,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
 #pragma unroll
         for (int k = 0; k < kCh; ++k) {
             if ((uint32_t)(k + kCh) < width) { // uniform
-                const uint32_t off = (k & 1) ? (hi.c[k >> 1] >> 16) : (hi.c[k >> 1] & 0xffffu);
+                const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
                 const double v = lds_ld(theta_l, off) * (double)slice_w<kDict>(hi, k, dict_l) * inv;
                 if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
             }
@@ -318,13 +330,13 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     }
     for (uint32_t j = 2 * kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = (j & 1) ? (cc >> 16) : (cc & 0xffffu);
+        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
         if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, bool kDict>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, int kDict>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles,
     const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict)
 {
-    __shared__ float dict_l[kDict ? 256 : 1]; // the distinct weights of a dictionary-coded store (oem_layout_dict.hip)
+    __shared__ float dict_l[kDict != kWPlain ? 256 : 1]; // the distinct weights of a coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         if (tile_index >= n_tiles) return;
     }
     const TileDesc td = tiles[tile_index]; // one 64-byte scalar load
-    const uint32_t ib = kDict ? i_base[tile_index] : 0u; // (requested with it)
+    const uint32_t ib = kDict == kWBytes ? i_base[tile_index] : 0u; // (requested with it)
     if (state && state->done) return;
     // per-cell batch: a FINISHED cell takes no part; a cell on its FINAL pass reads abundances below the
     // threshold as 0 (em.rs:238-242) -- done here, on the way in, instead of by a sweep over theta per pass
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         }
     }
     // (a slice's index words, when the weights are dictionary-coded)
-    auto iptr = [&](uint32_t q) -> const uint32_t * { return kDict ? widx + (size_t)ioff[q] * 64 : nullptr; };
+    auto iptr = [&](uint32_t q) -> const uint32_t * { return kDict == kWBytes ? widx + (size_t)ioff[q] * 64 : nullptr; };
 
     OEM_PROBE(1); // descriptor in hand, slice addresses derived
     // ---- every long-latency load of the tile is issued here, before any use ---------
@@ -408,12 +420,12 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
     }
     float dict_v = 0.0f;
-    if (kDict && tx < 256) dict_v = dict[tx]; // 1 KiB, L2-resident
+    if (kDict != kWPlain && tx < 256) dict_v = dict[tx]; // 1 KiB, L2-resident
     SliceRegs<WT, kCh> R[kSets];
     load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
     // alignments 8..15 of the first slice, into the second set (see fold_first)
     load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
-                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u, kDict ? iptr(0) + (kCh / 4) * 64 : nullptr);
+                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u, kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : nullptr);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         if (i < td.win_len) theta_l[i] = th(tw[u]);
     }
-    if (kDict && tx < 256) dict_l[tx] = dict_v;
+    if (kDict != kWPlain && tx < 256) dict_l[tx] = dict_v;
     for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 // remote alignments per thread in registers; 4 interleaved count-window copies for the narrow
 // window cap, one for the wide cap of sparse stores (40 KiB LDS; same-address atomics are rare
 // when few reads share a transcript).
-template <typename WT, bool kNT, bool kPacked, bool kDict>
+template <typename WT, bool kNT, bool kPacked, int kDict>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
                         const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
 {
@@ -646,16 +658,21 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
         if (t.packed) launch_tile<WT, NT, true, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);          \
         else launch_tile<WT, NT, false, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);                  \
     } while (0)
-    const bool dict = !f64w && t.dict_n > 0 && knob("OEM_NO_DICT", 0) == 0; // (knob: testing build, A/B)
+    // (a store whose codes carry the fused index has no other way to be read; the knob -- testing build, A/B --
+    // switches only the byte-stream coding off)
+    const bool bytes = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
     if (f64w) {
-        if (nt) OEM_TILE(double, true, t.w64, t.r_w64, false);
-        else OEM_TILE(double, false, t.w64, t.r_w64, false);
-    } else if (dict) {
-        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, true);
-        else OEM_TILE(float, false, t.w32, t.r_w32, true);
+        if (nt) OEM_TILE(double, true, t.w64, t.r_w64, kWPlain);
+        else OEM_TILE(double, false, t.w64, t.r_w64, kWPlain);
+    } else if (t.dict_fused) {
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, kWFused);
+        else OEM_TILE(float, false, t.w32, t.r_w32, kWFused);
+    } else if (bytes) {
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, kWBytes);
+        else OEM_TILE(float, false, t.w32, t.r_w32, kWBytes);
     } else {
-        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, false);
-        else OEM_TILE(float, false, t.w32, t.r_w32, false);
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, kWPlain);
+        else OEM_TILE(float, false, t.w32, t.r_w32, kWPlain);
     }
 #undef OEM_TILE
     OEM_HIP(hipGetLastError());

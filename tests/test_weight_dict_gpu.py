@@ -46,7 +46,7 @@ def test_coded_and_plain_weights_give_the_same_answer_and_the_oracles():
     assert_counts_close(res[0][3][0], res[1][3][0], st.n_reads, T, 1e-9, "coded vs plain, bootstrap replicate")
 
 
-@pytest.mark.parametrize("n_distinct,coded", [(3, True), (255, True), (256, False), (5000, False)])
+@pytest.mark.parametrize("n_distinct,coded", [(3, True), (127, True), (128, True), (255, True), (256, False), (5000, False)])
 def test_the_table_holds_at_most_256_values_including_the_zero_of_the_padding(n_distinct, coded):
     st = synth.make_store(40_000, 3_000, seed=7)
     rng = np.random.default_rng(n_distinct)
@@ -74,9 +74,11 @@ def test_continuous_and_coverage_weights_keep_their_streams():
         assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, "plain stream")
 
 
-def test_long_reads_take_the_reload_path_of_the_coded_weights():
+@pytest.mark.parametrize("n_values", [30, 200])
+def test_long_reads_take_the_reload_path_of_the_coded_weights(n_values):
     """Reads with more than 16 alignments inside one window: the coded weights of alignments 16.. are reloaded
-    by both passes of the fold (four indices per word), rows and slices of every width up to 60."""
+    by both passes of the fold, rows and slices of every width up to 60 -- with 30 distinct weights (index fused
+    into the window codes) and with 200 (index bytes in their own stream)."""
     rng = np.random.default_rng(12)
     R, T = 6_000, 900
     k = rng.integers(1, 61, size=R)
@@ -85,7 +87,8 @@ def test_long_reads_take_the_reload_path_of_the_coded_weights():
     rp[1:] = np.cumsum(k)
     base = rng.integers(0, T - 200, size=R)
     tid = np.concatenate([np.sort(rng.choice(200, size=int(kk), replace=False)) + b for kk, b in zip(k, base)]).astype(np.uint32)
-    p = np.exp(-rng.integers(0, 30, size=len(tid)) / 4.0).astype(np.float32)
+    p = np.exp(-rng.integers(0, n_values, size=len(tid)) / 40.0).astype(np.float32)
+    assert len(np.unique(p)) == n_values
     o = c_oracle.Store(rp, tid, p, None, T)
     want, wi = c_oracle.do_em(o, max_iter=60, conv_thresh=0.0)
     W = rng.poisson(1.0, size=R).astype(np.uint32)
