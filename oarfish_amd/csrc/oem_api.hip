@@ -567,7 +567,7 @@ void free_store(oem_store *s)
     hipFree(s->csr.w64);
     {
         oem::DeviceTiled &t = s->tiled;
-        hipFree(t.dict); hipFree(t.widx); hipFree(t.i_base);
+        hipFree(t.dict); hipFree(t.widx); hipFree(t.i_base); hipFree(t.r_wi);
         hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32);
         hipFree(t.w64); hipFree(t.r_tid); hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row);
         hipFree(t.r_slot); hipFree(t.r_pk); hipFree(t.sd); hipFree(t.q_dst); hipFree(t.bucket_base);

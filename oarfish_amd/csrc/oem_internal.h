@@ -128,6 +128,7 @@ struct DeviceTiled {
     float *dict = nullptr;         // 256 floats, ascending, [0] = 0.0
     uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles
     uint32_t *i_base = nullptr;    // n_tiles + 1: first index row of each tile
+    uint8_t *r_wi = nullptr;       // n_remote: table index of each remote record's weight
 };
 
 // ---------------------------------------------------------------------------

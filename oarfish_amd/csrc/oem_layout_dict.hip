@@ -136,6 +136,26 @@ __global__ __launch_bounds__(kDT) void k_dict_encode(const TileDesc *__restrict_
     }
 }
 
+// the remote records' weights -> one table index byte each
+__global__ __launch_bounds__(kDT) void k_dict_encode_remote(const float *__restrict__ r_w, uint64_t n, const float *__restrict__ dict,
+                                                            uint32_t n_dict, uint8_t *__restrict__ r_wi, uint32_t *bad)
+{
+    __shared__ uint32_t keys[256];
+    keys[threadIdx.x] = threadIdx.x < n_dict ? __float_as_uint(dict[threadIdx.x]) : 0x7f800000u;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * kDT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kDT) {
+        const uint32_t key = __float_as_uint(r_w[i]);
+        uint32_t a = 0, b = n_dict;
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (keys[mid] < key) a = mid + 1;
+            else b = mid;
+        }
+        if (a >= n_dict || keys[a] != key) { *bad = 1u; a = 0; }
+        r_wi[i] = (uint8_t)a;
+    }
+}
+
 // <= 128 distinct weights: the index goes into the spare bits of the alignment's own window code (bits 0..2 and
 // 12..15 of its 16-bit half; the code is 8 * (transcript - lo) < 4096), no index stream
 __global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ tiles, const float *__restrict__ w,
@@ -205,6 +225,12 @@ int build_weight_dictionary(oem_store *s)
         uint64_t g = (n + kDT - 1) / kDT;
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(k_dict_collect, dim3((uint32_t)g), dim3(kDT), 0, st, t.w32, n, limit, gtab, small, small + 1);
+        if (t.n_remote) { // the remote records' weights come from the same table
+            uint64_t gr = (t.n_remote + kDT - 1) / kDT;
+            if (gr > 2048) gr = 2048;
+            hipLaunchKernelGGL(k_dict_collect, dim3((uint32_t)gr), dim3(kDT), 0, st, t.r_w32, t.n_remote, limit, gtab, small,
+                               small + 1);
+        }
         OEM_HIP(hipGetLastError());
         uint32_t h_small[4];
         std::vector<uint32_t> h_tab(kSetSlots);
@@ -224,6 +250,17 @@ int build_weight_dictionary(oem_store *s)
         for (size_t i = 0; i < keys.size(); ++i) std::memcpy(&dict[i], &keys[i], sizeof(float));
         OEM_HIP(hipMalloc((void **)&t.dict, sizeof(float) * 256));
         OEM_HIP(hipMemcpyAsync(t.dict, dict.data(), sizeof(float) * 256, hipMemcpyHostToDevice, st));
+        {   // remote records: one index byte instead of the f32 (kept for the batched kernel)
+            OEM_HIP(hipMalloc((void **)&t.r_wi, t.n_remote ? t.n_remote : 1));
+            s->hbm_bytes += t.n_remote;
+            if (t.n_remote) {
+                uint64_t gr = (t.n_remote + kDT - 1) / kDT;
+                if (gr > 4096) gr = 4096;
+                hipLaunchKernelGGL(k_dict_encode_remote, dim3((uint32_t)gr), dim3(kDT), 0, st, t.r_w32, t.n_remote, t.dict,
+                                   (uint32_t)keys.size(), t.r_wi, small + 2);
+                OEM_HIP(hipGetLastError());
+            }
+        }
         if (keys.size() <= 128 && knob("OEM_DICT_NO_FUSE", 0) == 0) { // (knob: testing build, reaches the byte-stream coding)
             // the index fits the spare bits of the window codes: no stream of its own
             hipLaunchKernelGGL(k_dict_fuse, dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict, (uint32_t)keys.size(),
@@ -261,8 +298,10 @@ int build_weight_dictionary(oem_store *s)
         if (h_small[2]) { // (cannot happen: every weight was collected) -- fall back to the f32 stream
             hipFree(t.widx);
             hipFree(t.dict);
+            hipFree(t.r_wi);
             t.widx = nullptr;
             t.dict = nullptr;
+            t.r_wi = nullptr;
             return OEM_OK;
         }
         t.i_base = begins;

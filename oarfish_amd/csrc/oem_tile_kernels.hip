@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     double *__restrict__ queue, const double *__restrict__ theta, double *__restrict__ cnt,
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
     const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles,
-    const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict)
+    const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict,
+    const uint8_t *__restrict__ r_wi)
 {
     __shared__ float dict_l[kDict != kWPlain ? 256 : 1]; // the distinct weights of a coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
@@ -430,11 +431,13 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
     uint32_t rslot[kRem]; // their slot in the bucket-major queue
+    constexpr bool kRemIdx = kDict != kWPlain; // coded stores: a remote record's weight is a table index byte too
     const uint32_t tid_base = td.problem * problem_size; // first transcript of the tile's EM problem (0: one problem)
     const uint32_t *sd_t = sd + td.sd_begin - td.b_min;  // slot of record i = sd_t[bucket of its transcript] + i
     {
         uint32_t rt[kRem];
         WT rw[kRem];
+        uint32_t ri[kRem]; // coded stores: the remote weights are table indices too, one byte each (index 0 = 0.0)
         if (td.remote_cnt) { // wave-uniform
             // branch-free: out-of-range slots re-read the tile's last record and carry no weight,
             // so the loads issue back to back
@@ -444,17 +447,20 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
                 ld_remote<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
-                rw[k] = ld_stream<kNT>(&r_w[o]);
+                if (kRemIdx) ri[k] = ld_stream<kNT>(&r_wi[o]);
+                else rw[k] = ld_stream<kNT>(&r_w[o]);
             }
 #pragma unroll
             for (int k = 0; k < kRem; ++k)
-                if (tx + k * kTileThreads >= td.remote_cnt) rw[k] = (WT)0;
+                if (tx + k * kTileThreads >= td.remote_cnt) { rw[k] = (WT)0; ri[k] = 0u; }
         } else {
 #pragma unroll
-            for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
+            for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; ri[k] = 0u; rrow[k] = 0; }
         }
+        // (coded: the weight comes from the 1 KiB table in memory -- L1-resident -- in the same round trip as theta)
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) rx[k] = th(theta[rt[k]]) * (double)rw[k];
+        for (int k = 0; k < kRem; ++k)
+            rx[k] = th(theta[rt[k]]) * (kRemIdx ? (double)dict[ri[k]] : (double)rw[k]);
         // the slots are wanted last (phase B): a few words per tile, cache-resident.  Branch-free and back to
         // back -- a lookup per branch made the compiler wait for each one in turn, six dependent round trips
         // (a tile without remote records reads the table's slack word)
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t o = td.remote_begin + i;
         uint32_t t, row;
         ld_remote<kPacked, false>(r_a, r_row, o, tid_base, t, row);
-        const double x = th(theta[t]) * (double)r_w[o];
+        const double x = th(theta[t]) * (kRemIdx ? (double)dict[r_wi[o]] : (double)r_w[o]);
         queue[sd_t[t >> kBucketShift] + i] = x;
         lds_add_f64(&den_l[row], x);
     }
@@ -621,11 +627,11 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     if (t.win_cap > kWin)
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict);
+                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict, t.r_wi);
     else
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict);
+                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict, t.r_wi);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)
