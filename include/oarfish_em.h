@@ -78,8 +78,9 @@ typedef struct {
                               device builder declines); 1 = always the host builder (oem_layout.cpp, the
                               specification the device builder is tested against) */
     uint32_t weight_coding; /* 0 = a store with at most 256 distinct f32 weights (as_prob is exp of an integer score
-                              gap over a constant: tens to hundreds of values) keeps its local weights as one-byte
-                              indices into a table of them -- lossless; 1 = always the f32 stream (was reserved[0]) */
+                              gap over a constant: tens to hundreds of values) keeps its weights as indices into a
+                              table of them -- in the spare bits of the window codes up to 128 values, a byte each up
+                              to 256; lossless, oem_layout_dict.hip; 1 = always the f32 stream (was reserved[0]) */
     uint32_t reserved[3];
 } oem_store_opts;
 
