@@ -72,6 +72,10 @@ __global__ __launch_bounds__(kDT) void k_dict_collect(const float *__restrict__ 
         const uint32_t key = __float_as_uint(w[i]);
         if (key == last) continue;
         last = key;
+        if (key & 0x80000000u) { // a negative weight, -0.0 or a negative NaN: not ordered like its bits -- keep the f32 stream
+            *too_many = 1u;
+            break;
+        }
         // (almost every value is in the set already: a plain read of its slot -- a broadcast when the lanes agree --
         // before the compare-and-swap that would serialise them)
         if (((volatile uint32_t *)tab)[mix32(key) & (kSetSlots - 1)] == key) continue;

@@ -107,3 +107,16 @@ def test_unknown_info_key_is_an_argument_error():
     with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
         with pytest.raises(Exception):
             d.info(99)
+
+
+def test_a_negative_zero_weight_keeps_the_f32_stream():
+    """-0.0 (or any pattern with the sign bit) is not ordered like its bits: such a store is not coded, and runs."""
+    st = synth.make_store(8_000, 600, seed=3)
+    p = st.as_prob.copy()
+    p[5] = np.float32(-0.0)
+    o = c_oracle.Store(st.row_ptr, st.tid, p, None, st.n_txps)
+    want, _ = c_oracle.do_em(o, max_iter=20, conv_thresh=0.0)
+    with DeviceStore(st.row_ptr, st.tid, p, None, st.n_txps) as d:
+        assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0
+        got, _ = d.em_run(None, 20, 0.0, 50)
+    assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, "store with a -0.0 weight")
