@@ -8,7 +8,7 @@
 // -- a local alignment is then its two code bytes and nothing else -- with 129..256 as BYTES, four indices per u32
 // in the tiles' SELL layout (1 + 2 bytes per local alignment).  The f32 stream costs 4 + 2.  The table sits in
 // 1 KiB of LDS per workgroup, and the value the kernel multiplies with is bit for bit the f32 the caller handed
-// over -- lossless, no tolerance involved.  Measured at C3 (25 distinct weights): the pass
+// over -- lossless, no tolerance involved.  Measured at C3 (98 distinct weights): the pass
 // 0.199 -> 0.176 ms (profiles/r03_notes.md): the pass follows its bytes.
 //
 // Stores with more distinct weights, f64 weights (the coverage model multiplies a second factor in) or the wide
