@@ -336,8 +336,15 @@ int oem_comm_p2p_connect(oem_comm *comm, const void *all_handles /* n_ranks x OE
  * the peer-to-peer exchange when the communicator also has RCCL (default 4 MB; 0 = always RCCL).
  * OEM_COMM_OPT_P2P_SHAPE: 0 (default) = by the number of ranks and the vector's size, 1 = one-shot (every rank reads every
  * partial whole), 2 = two-phase (rank r sums slice r, then every rank reads the reduced slices from their
- * owners: a quarter of the bytes per xGMI link at 8 ranks for one more flag round); oem_p2p.hip. */
-typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1, OEM_COMM_OPT_P2P_SHAPE = 2 } oem_comm_option;
+ * owners: a quarter of the bytes per xGMI link at 8 ranks for one more flag round); oem_p2p.hip.
+ * OEM_COMM_OPT_P2P_TIMEOUT_MS: bound of one wait for a peer inside an exchange kernel, in milliseconds (default
+ * 8000; a wait that gives up ends the run with OEM_ERR_STATE instead of hanging the GPU).
+ * OEM_COMM_OPT_P2P_SELF_CHECK (set BEFORE oem_comm_p2p_connect): 1 = connect ends with a checked exchange in both
+ * shapes against a closed-form sum -- also the ranks' rendezvous, with a long wait (120 s), so a peer that is still
+ * building its store does not time the EM loop's first exchange out.  Needs every rank inside connect at the same
+ * time (ranks = processes); a failure leaves the peer-to-peer backend disconnected (RCCL, if any, carries on). */
+typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1, OEM_COMM_OPT_P2P_SHAPE = 2, OEM_COMM_OPT_P2P_TIMEOUT_MS = 3,
+               OEM_COMM_OPT_P2P_SELF_CHECK = 4 } oem_comm_option;
 int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t value);
 
 /* Declare `store` to be rank-local row shard of a store with

@@ -25,6 +25,8 @@ OEM_OPT_BATCH_BOOTSTRAP = 1
 OEM_OPT_BOOTSTRAP_FIRST_REPLICA = 2
 OEM_COMM_OPT_P2P_MAX_BYTES = 1
 OEM_COMM_OPT_P2P_SHAPE = 2
+OEM_COMM_OPT_P2P_TIMEOUT_MS = 3
+OEM_COMM_OPT_P2P_SELF_CHECK = 4
 OEM_INFO_WEIGHT_DICT_ENTRIES = 1
 OEM_INFO_TILES = 2
 OEM_INFO_REMOTE_ALIGNMENTS = 3

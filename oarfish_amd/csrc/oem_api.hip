@@ -341,8 +341,7 @@ int ensure_batch(oem_store *s, int chain)
     else OEM_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
     OEM_TRY(dev_alloc(&b.d_row_w, s->csr.n_reads, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.theta, T * kBatch, &s->hbm_bytes));
-    OEM_TRY(dev_alloc(&b.cnt, 2 * T * kBatch, &s->hbm_bytes));
-    b.cnt2 = b.cnt + T * kBatch;
+    OEM_TRY(dev_alloc(&b.cnt, T * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.out, T * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.queue, (size_t)s->tiled.n_remote * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
@@ -351,7 +350,7 @@ int ensure_batch(oem_store *s, int chain)
     // a slot that is never handed a replicate (n_boot < kBatch, the tail of a chain) is still swept by the
     // tile kernel's four-slot epoch: its columns must hold zeros, not whatever hipMalloc returned
     OEM_HIP(hipMemsetAsync(b.theta, 0, sizeof(double) * T * kBatch, b.stream));
-    OEM_HIP(hipMemsetAsync(b.cnt, 0, sizeof(double) * 2 * T * kBatch, b.stream));
+    OEM_HIP(hipMemsetAsync(b.cnt, 0, sizeof(double) * T * kBatch, b.stream));
     OEM_HIP(hipMemsetAsync(b.out, 0, sizeof(double) * T * kBatch, b.stream));
     OEM_HIP(hipMemsetAsync(b.queue, 0, sizeof(double) * (size_t)s->tiled.n_remote * kBatch, b.stream));
     OEM_TRY(dev_alloc(&b.overflow, 1, &s->hbm_bytes));
@@ -378,6 +377,7 @@ int agree_any(oem_store *s, bool *flag)
     double r = 0.0;
     OEM_HIP(hipMemcpyAsync(&r, d, sizeof(double), hipMemcpyDeviceToHost, s->stream));
     OEM_HIP(hipStreamSynchronize(s->stream));
+    OEM_TRY(comm_check(s->comm, s->stream)); // a timed-out exchange would leave ranks disagreeing on the flag
     *flag = r != 0.0;
     return OEM_OK;
 }
@@ -413,7 +413,7 @@ int run_bootstrap_chain(oem_store *s, int chain, BootJob *job)
     EmParams p{T, job->max_iter, 50u /* do_bootstrap -> do_em, em.rs:289,:212 */, job->conv_thresh};
     const bool sharded = comm_exchanges(s->comm);
     int slot_rep[kBatch];
-    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, st));
+    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * T * kBatch, st));
     for (int k = 0; k < kBatch; ++k) {
         slot_rep[k] = -1;
         std::memset(&bb.h_state[k], 0, sizeof(BatchState));
@@ -437,6 +437,7 @@ int run_bootstrap_chain(oem_store *s, int chain, BootJob *job)
             uint32_t h_overflow = 0;
             OEM_HIP(hipMemcpyAsync(&h_overflow, bb.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             OEM_HIP(hipStreamSynchronize(st));
+            if (sharded) OEM_TRY(comm_check(s->comm, st)); // (the passes queued before this hand-over exchanged)
             bool over = h_overflow != 0;
             OEM_TRY(agree_any(s, &over)); // row shards (one chain): every rank must route the replicate the same way
             if (over) { // a multiplicity >= 256: this replicate goes to the one-per-pass path
@@ -456,11 +457,11 @@ int run_bootstrap_chain(oem_store *s, int chain, BootJob *job)
 
     auto one_pass = [&]() -> int {
         OEM_TRY(launch_batch_pass(s, bb));
-        if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, 2 * (size_t)T * kBatch, st));
+        if (sharded) OEM_TRY(comm_allreduce_sum_f64(s->comm, bb.cnt, bb.cnt, (size_t)T * kBatch, st));
         return launch_batch_reldiff(s, bb, p);
     };
     ChunkGraph cg; // kGraphIters batched passes, replayed (see capture_chunk)
-    if (graph_ok(s, 2 * (size_t)T * kBatch) && job->max_iter >= 4 * kGraphIters)
+    if (graph_ok(s, (size_t)T * kBatch) && job->max_iter >= 4 * kGraphIters)
         OEM_TRY(capture_chunk(st, kGraphIters, one_pass, &cg));
     bool first = true;
     for (;;) {
@@ -477,12 +478,15 @@ int run_bootstrap_chain(oem_store *s, int chain, BootJob *job)
         }
         OEM_HIP(hipMemcpyAsync(bb.h_state, bb.state, sizeof(BatchState) * kBatch, hipMemcpyDeviceToHost, st));
         OEM_HIP(hipStreamSynchronize(st));
+        // a peer that never arrived: the waits gave up and the passes summed stale slots -- an error, not replicates
+        if (sharded) OEM_TRY(comm_check(s->comm, st));
         for (int k = 0; k < kBatch; ++k) {
             if (slot_rep[k] < 0 || bb.h_state[k].phase != kPhaseFinished) continue;
             const uint32_t rep = (uint32_t)slot_rep[k];
             OEM_HIP(hipMemcpyAsync(bb.h_out + (size_t)k * T, bb.out + (size_t)k * T, sizeof(double) * T,
                                    hipMemcpyDeviceToHost, st));
             OEM_HIP(hipStreamSynchronize(st));
+            if (sharded) OEM_TRY(comm_check(s->comm, st));
             std::memcpy(job->out + (size_t)rep * T, bb.h_out + (size_t)k * T, sizeof(double) * T);
             if (job->infos) {
                 job->infos[rep].niter = bb.h_state[k].niter;
@@ -584,6 +588,7 @@ void free_store(oem_store *s)
         if (b.h_out) hipHostFree(b.h_out);
     }
     hipFree(s->multi.state); hipFree(s->multi.out); hipFree(s->multi.n_unfinished);
+    hipFree(s->multi.live_tiles); hipFree(s->multi.live_buckets); hipFree(s->multi.d_live_counts);
     hipFree(s->theta);
     hipFree(s->cnt);
     hipFree(s->d_state);
@@ -1199,7 +1204,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             // store without remote alignments has no buckets to own and takes the separate kernels
             const bool fused_fold = s->tiled.n_remote > 0 && s->tiled.n_buckets > 0 && knob("OEM_CELLS_FUSED_FOLD", 1) != 0;
             uint64_t launched = 0;
-            uint32_t unfinished = n_cells;
+            uint32_t unfinished = n_cells, compacted_at = n_cells;
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess ||
                 hipEventRecord(ev0, s->stream) != hipSuccess) {
@@ -1234,6 +1239,12 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
                     hipStreamSynchronize(s->stream) != hipSuccess) {
                     rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: state read-back failed");
                     break;
+                }
+                // cells have finished since the live lists were built: the next passes launch the live tiles and
+                // buckets only (the lists stay supersets of the live work until the next look)
+                if (unfinished && unfinished < compacted_at && !cg.ready() && knob("OEM_CELLS_COMPACT", 1) != 0) {
+                    rc2 = multi_compact_live(s, mb);
+                    compacted_at = unfinished;
                 }
             }
             if (rc2 == OEM_OK && hipEventRecord(ev1, s->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess) {
@@ -1565,7 +1576,7 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
     const uint32_t T = s->csr.n_txps;
     const uint64_t R = s->csr.n_reads;
     const double avg = (double)s->global_n_reads / (double)T;
-    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * 2 * T * kBatch, s->stream));
+    OEM_HIP(hipMemsetAsync(bb.cnt, 0, sizeof(double) * T * kBatch, s->stream));
     for (int k = 0; k < kBatch; ++k) { // every slot RUNNING on its own device-drawn resample
         OEM_TRY(launch_bootstrap_weights(s, bb.d_row_w, R, s->global_row_offset, s->global_n_reads, 0x7e57ull, (uint32_t)k));
         OEM_HIP(hipMemsetAsync(bb.overflow, 0, sizeof(uint32_t), s->stream));

@@ -14,6 +14,17 @@
 // not shared, and measured it is what the pass costs: ~150 us per slot at 4, 8 or 16 slots
 // (profiles/r02_notes.md) -- hence kBatch = 4 (one epoch) and two chains, which overlap.
 //
+// Factored increments (round 4).  em.rs:119-130 adds theta_t * w / denom per alignment; the sum over the
+// reads of a tile factors as theta_t * sum_i (w_it * c_i / denom_i), so the scatter pass adds u = w * (c / denom)
+// -- no second LDS read of theta per (alignment, slot) -- and theta is multiplied in ONCE per window entry when
+// the window is flushed (and once per bucket entry by the fold, for the remote alignments: a queue entry is
+// w * c / denom).  Same value up to rounding (one multiplication moved across the sum); it halves the LDS reads
+// of the local phase and frees the 24 registers that held theta * w of the remote records across it.
+// A remote alignment's queue entry is ONE 32-byte piece [record][slot] (one store instead of four into four
+// planes), and k_remote_fold_b folds the four slots of a bucket in one workgroup (4096 transcripts x 4 slots x
+// 8 B = 128 KiB of LDS): the destinations are read once, not once per slot, and the counts of both kernels land
+// in the one [T][slot] array.
+//
 // k_em_tile_e: one workgroup per tile, the tile's matrix data loaded ONCE into registers,
 // then kE "epochs" of kEB = 4 slots each run over it: per epoch the theta window, the count
 // window and the denominators of 4 slots live in LDS (64 KiB per workgroup => two workgroups
@@ -209,7 +220,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
             const double wk = (double)lo.w[k];
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
-                const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                const double v = wk * inv[j]; // (theta is multiplied in when the window is flushed)
                 if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
             }
         }
@@ -225,7 +236,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
                 const double wk = (double)hi.w[k];
 #pragma unroll
                 for (int j = 0; j < kEB; ++j) {
-                    const double v = lds_ld_b(theta_l, off + rot8[j]) * wk * inv[j];
+                    const double v = wk * inv[j];
                     if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
                 }
             }
@@ -241,7 +252,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
             const double wk = (double)wv[m];
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
-                const double v = lds_ld_b(theta_l, off4[m] + rot8[j]) * wk * inv[j];
+                const double v = wk * inv[j];
                 if (v != 0.0) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
             }
         }
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd, uint32_t problem_size,
-    double *__restrict__ queue /* [kB][n_remote] */, uint64_t n_remote,
+    double *__restrict__ queue /* [n_remote][kB]: w * c / denom of every remote alignment, the slots side by side */,
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
 {
@@ -403,8 +414,8 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         }
         // multiplicities of the reads of this thread's remote records (4 KB per tile: cache-resident).  A read
         // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote
-        // denominators are never read and its queue entries stay at the zero the slot was loaded with
-        // (launch_batch_reset_slot clears the slot's queue plane), so neither is touched.
+        // denominators are never read (no LDS atomics for them) and its c / denom is 0, so its queue entries
+        // are written as zeros with the 32-byte piece they share with the other slots.
         uint32_t rmult[kRemE]; // (loaded branch-free and back to back; a thread without a record discards its word)
 #pragma unroll
         for (int k = 0; k < kRemE; ++k)
@@ -447,19 +458,14 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                 for (int b = 0; b < kEB; ++b)
                     if ((rmult[k] >> (8 * b)) & 0xffu) lds_add(&den_l[b * kTileRows + rrow[k]], rx[k][b]);
             }
-        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // overflow: park x in the queue
+        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // beyond the register-resident records
             const uint32_t o = td.remote_begin + i;
             uint32_t t, row;
             ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
-            const uint32_t q = sd_t[t >> kBucketShift] + i;
             const double *tp = theta + (size_t)t * kB + eoff;
             const double wv = (double)r_w[o];
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) {
-                const double x = th(tp[b], b) * wv;
-                queue[(eoff + b) * n_remote + q] = x;
-                lds_add(&den_l[b * kTileRows + row], x);
-            }
+            for (int b = 0; b < kEB; ++b) lds_add(&den_l[b * kTileRows + row], th(tp[b], b) * wv);
         }
         OEM_PROBE_E(4);
         __syncthreads();
@@ -508,30 +514,31 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         __syncthreads();
         OEM_PROBE_E(8);
 
-        // ---- remote phase B: queue[slot][.] <- x_b * (c_ib / denom_ib) -------------------------
+        // ---- remote phase B: queue[record][.] <- w * (c_ib / denom_ib), the epoch's slots as one 32-byte piece ----
 #pragma unroll
         for (int k = 0; k < kRemE; ++k) {
-            if (rmult[k]) {
+            if (tx + k * kTileThreadsE < td.remote_cnt) {
+                double *qp = queue + (size_t)rslot[k] * kB + eoff;
+                const double wv = (double)rw[k];
+                double qv[kEB];
 #pragma unroll
-                for (int b = 0; b < kEB; ++b)
-                    if ((rmult[k] >> (8 * b)) & 0xffu)
-                        queue[(eoff + b) * n_remote + rslot[k]] = rx[k][b] * den_l[b * kTileRows + rrow[k]];
+                for (int b = 0; b < kEB; ++b) qv[b] = wv * den_l[b * kTileRows + rrow[k]];
+#pragma unroll
+                for (int b = 0; b < kEB; ++b) qp[b] = qv[b];
             }
         }
         for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
             const uint32_t o = td.remote_begin + i;
             uint32_t t, row;
             ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
-            const uint32_t q = sd_t[t >> kBucketShift] + i;
+            double *qp = queue + (size_t)(sd_t[t >> kBucketShift] + i) * kB + eoff;
+            const double wv = (double)r_w[o];
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) {
-                const size_t qi = (eoff + b) * n_remote + q;
-                queue[qi] = queue[qi] * den_l[b * kTileRows + row];
-            }
+            for (int b = 0; b < kEB; ++b) qp[b] = wv * den_l[b * kTileRows + row];
         }
-        // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b] --------------------------
+        // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b], theta multiplied in here --------
         for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) {
-            const double v = cnt_l[i];
+            const double v = cnt_l[i] * theta_l[i];
             if (v != 0.0) unsafeAtomicAdd(&cnt[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], v);
         }
         OEM_PROBE_E(9);
@@ -539,57 +546,95 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     }
 }
 
-// one workgroup per (slot, bucket, group): streams queue[slot][range] into an LDS window and
-// flushes it into cnt2[slot][.] (slot-major, so the flush is line-coalesced)
+// One workgroup per (bucket, group[, four slots of kB]): streams its range of queue entries -- the 32-byte piece of
+// its four slots -- into an LDS window of kBucket transcripts x 4 slots (128 KiB: one workgroup per CU), then
+// flushes theta * sum into cnt[t][slot] (theta is multiplied in here, once per bucket entry: see "factored
+// increments" at the top).  The destinations q_dst are read once for the four slots.  A thread takes 16 bytes
+// (two slots) of an entry, consecutive lanes consecutive pieces, eight loads in flight: with one 16-wavefront
+// workgroup per CU it takes 128 KiB in flight per CU to keep the memory system busy (4 x 8 bytes per thread, the
+// first version, ran the kernel at its latency, not at its bytes).
+constexpr int kFS = 4;       // slots per fold workgroup
+constexpr int kFoldDepth = 8; // loads in flight per thread
 __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
-    const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue, uint64_t n_remote,
-    const uint16_t *__restrict__ q_dst, double *__restrict__ cnt2 /* [kB][T] */,
-    const BatchState *__restrict__ st, uint32_t n_groups, uint32_t n_buckets, uint32_t n_txps)
+    const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue /* [n_remote][kB] */,
+    const uint16_t *__restrict__ q_dst, const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
+    const BatchState *__restrict__ st, uint32_t n_groups, uint32_t n_txps)
 {
-    const uint32_t b = blockIdx.x / (n_groups * n_buckets);
-    if (st[b].phase == kPhaseFinished) return;
-    const uint32_t rest = blockIdx.x % (n_groups * n_buckets);
-    const uint32_t bk = rest / n_groups, g = rest % n_groups;
-    __shared__ double acc[kBucket];
+    const uint32_t s_first = blockIdx.y * kFS; // first slot of this workgroup
+    uint32_t act = 0, fin = 0;
+#pragma unroll
+    for (int b = 0; b < kFS; ++b) {
+        const uint32_t ph = st[s_first + b].phase;
+        act |= (ph != kPhaseFinished) ? (1u << b) : 0u;
+        fin |= (ph == kPhaseFinal) ? (1u << b) : 0u;
+    }
+    if (!act) return;
+    const uint32_t bk = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
+    extern __shared__ double acc[]; // [kBucket][kFS]
     const uint32_t q0 = bucket_base[bk], q1 = bucket_base[bk + 1];
     const uint64_t span = q1 - q0;
     const uint32_t s0 = q0 + (uint32_t)(span * g / n_groups);
     const uint32_t s1 = q0 + (uint32_t)(span * (g + 1) / n_groups);
     if (s0 == s1) return;
-    for (uint32_t i = threadIdx.x; i < kBucket; i += kFoldThreadsB) acc[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < kBucket * kFS; i += kFoldThreadsB) acc[i] = 0.0;
     __syncthreads();
-    const double *qb = queue + (size_t)b * n_remote;
-    uint32_t o = s0 + threadIdx.x;
-    for (; o + 3 * kFoldThreadsB < s1; o += 4 * kFoldThreadsB) {
-        double v[4];
-        uint32_t d[4];
+    const uint32_t half = threadIdx.x & 1u;               // which two of the four slots
+    constexpr uint32_t kEntriesPerStep = kFoldThreadsB / 2; // entries one load of the workgroup covers
+    struct alignas(16) D2 { double x, y; };
+    const D2 *q2 = reinterpret_cast<const D2 *>(queue);
+    auto piece = [&](uint32_t o) -> const D2 * { return q2 + ((size_t)o * kB + s_first) / 2 + half; };
+    uint32_t o = s0 + (threadIdx.x >> 1);
+    for (; o + (kFoldDepth - 1) * kEntriesPerStep < s1; o += kFoldDepth * kEntriesPerStep) {
+        D2 v[kFoldDepth];
+        uint32_t d[kFoldDepth];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = qb[o + k * kFoldThreadsB];
-            d[k] = q_dst[o + k * kFoldThreadsB];
+        for (int k = 0; k < kFoldDepth; ++k) {
+            v[k] = *piece(o + k * kEntriesPerStep);
+            d[k] = q_dst[o + k * kEntriesPerStep];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (v[k] != 0.0) lds_add(&acc[d[k]], v[k]);
+        for (int k = 0; k < kFoldDepth; ++k) {
+            double *a = &acc[d[k] * kFS + 2 * half];
+            if (v[k].x != 0.0) lds_add(a, v[k].x);
+            if (v[k].y != 0.0) lds_add(a + 1, v[k].y);
+        }
     }
-    for (; o < s1; o += kFoldThreadsB) {
-        const double v = qb[o];
-        if (v != 0.0) lds_add(&acc[q_dst[o]], v);
+    for (; o < s1; o += kEntriesPerStep) {
+        const D2 v = *piece(o);
+        double *a = &acc[(uint32_t)q_dst[o] * kFS + 2 * half];
+        if (v.x != 0.0) lds_add(a, v.x);
+        if (v.y != 0.0) lds_add(a + 1, v.y);
     }
     __syncthreads();
+    // flush: thread i takes window elements i, i + 1024, ...: (transcript, slot) pairs in [t][slot] order -- for
+    // kB == kFS consecutive lanes on consecutive doubles of theta and cnt.  Four elements per round trip.
     const uint32_t base = bk * kBucket;
-    for (uint32_t i = threadIdx.x; i < kBucket && base + i < n_txps; i += kFoldThreadsB) {
-        const double v = acc[i];
-        if (v != 0.0) unsafeAtomicAdd(&cnt2[(size_t)b * n_txps + base + i], v);
+    const uint32_t slot = threadIdx.x % kFS; // (kFoldThreadsB is a multiple of kFS)
+    static_assert(kFoldThreadsB % kFS == 0, "slot of a thread = thread index mod kFS");
+    if (!((act >> slot) & 1u)) return;       // (a finished slot's entries are zeros: nothing of it to flush)
+    const bool final_slot = (fin >> slot) & 1u;
+    for (uint32_t i0 = threadIdx.x; i0 < kBucket * kFS; i0 += 4 * kFoldThreadsB) {
+        double v[4], th[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * kFoldThreadsB, t = base + i / kFS;
+            v[k] = (i < kBucket * kFS && t < n_txps) ? acc[i] : 0.0;
+            th[k] = v[k] != 0.0 ? theta[(size_t)t * kB + s_first + slot] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * kFoldThreadsB, t = base + i / kFS;
+            if (final_slot && th[k] < OEM_MIN_READ_THRESH) th[k] = 0.0; // em.rs:238-242, as k_em_tile_e reads it
+            const double x = v[k] * th[k];
+            if (x != 0.0) unsafeAtomicAdd(&cnt[(size_t)t * kB + s_first + slot], x);
+        }
     }
 }
 
-// rel-diff / swap / clear / state machine for kB slots (em.rs:194-218, :238-254)
-//   curr_b[t] = cnt[t][b] + cnt2[b][t]
+// rel-diff / swap / clear / state machine for kB slots (em.rs:194-218, :238-254); curr_b[t] = cnt[t][b]
 constexpr int kRelB = 1024; // as k_reldiff_swap_clear: few fat workgroups, the state-line atomics serialise
 __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
-                                                   double *__restrict__ cnt2, double *__restrict__ out,
-                                                   BatchState *st, EmParams p)
+                                                   double *__restrict__ out, BatchState *st, EmParams p)
 {
     uint32_t running = 0, final_ = 0; // SGPR masks
 #pragma unroll
@@ -600,7 +645,7 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     }
     if (!(running | final_)) return;
     // One (transcript, slot) element per thread per step, consecutive threads on consecutive elements of
-    // the [T][kB] arrays (fully coalesced; cnt2[b][.] is read in runs of 64 / kB transcripts).  The stride
+    // the [T][kB] arrays (fully coalesced).  The stride
     // is a multiple of kB, so a thread stays on ONE slot, b = thread index mod kB, and the maxima of the kB
     // slots are the kB residue classes of the lanes.
     static_assert((kRelB % kB) == 0 && (64 % kB) == 0, "slot of a lane = lane mod kB");
@@ -611,9 +656,8 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_elem; j += (size_t)gridDim.x * blockDim.x) {
         if (!is_live) continue;
         const size_t i = j / kB, ib = (size_t)b * p.n_txps + i;
-        const double cc = cnt[j] + cnt2[ib];
+        const double cc = cnt[j];
         cnt[j] = 0.0;
-        cnt2[ib] = 0.0;
         if (is_final) {
             out[ib] = cc;                               // em.rs:254
         } else {
@@ -672,13 +716,12 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
 
 // (re)start of ONE slot of the rolling batch: theta[t][slot] = init / avg, its counts cleared
 __global__ __launch_bounds__(256) void k_reset_slot_b(double *__restrict__ theta, double *__restrict__ cnt,
-                                                      double *__restrict__ cnt2, const double *__restrict__ init,
-                                                      double avg, uint32_t n_txps, uint32_t slot)
+                                                      const double *__restrict__ init, double avg, uint32_t n_txps,
+                                                      uint32_t slot)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_txps; i += gridDim.x * blockDim.x) {
         theta[(size_t)i * kB + slot] = init ? init[i] : avg;
         cnt[(size_t)i * kB + slot] = 0.0;
-        cnt2[(size_t)slot * n_txps + i] = 0.0;
     }
 }
 
@@ -718,7 +761,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 #define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK)                                                                         \
     hipLaunchKernelGGL((k_em_tile_e<NT, WT, PK>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes, \
                        (const WT *)W, PK ? t.r_pk : t.r_tid, (const WT *)RW, t.r_row, t.sd, t.problem_size, bb.queue,    \
-                       t.n_remote, bb.theta, bb.cnt, bb.state, bb.row_w)
+                       bb.theta, bb.cnt, bb.state, bb.row_w)
 #define OEM_LAUNCH_TILE_E(NT, WT, W, RW)                                                                              \
     do {                                                                                                              \
         if (t.packed) OEM_LAUNCH_TILE_E2(NT, WT, W, RW, true);                                                        \
@@ -735,14 +778,20 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 #undef OEM_LAUNCH_TILE_E
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0) {
+        // one 128 KiB workgroup per CU; every group clears and flushes a whole window, which pays from ~32 Ki entries
         uint32_t n_groups = 256 / (t.n_buckets ? t.n_buckets : 1);
         const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
         const uint32_t max_useful = (uint32_t)((per_bucket + 32767) / 32768);
         if (n_groups > max_useful) n_groups = max_useful;
         if (n_groups < 1) n_groups = 1;
-        hipLaunchKernelGGL(k_remote_fold_b, dim3(kB * t.n_buckets * n_groups), dim3(kFoldThreadsB), 0, bb.stream,
-                           t.bucket_base, bb.queue, t.n_remote, t.q_dst, bb.cnt2, bb.state, n_groups,
-                           t.n_buckets, s->csr.n_txps);
+        constexpr size_t kFoldLds = sizeof(double) * kBucket * kFS;
+        static_assert(kB % kFS == 0, "the fold takes the slots four at a time");
+        static_assert(kFoldLds <= 160u * 1024u, "the fold window of all slots must fit the LDS of a CU");
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_remote_fold_b),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFoldLds);
+        OEM_HIP(attr);
+        hipLaunchKernelGGL(k_remote_fold_b, dim3(t.n_buckets * n_groups, kB / kFS), dim3(kFoldThreadsB), kFoldLds, bb.stream,
+                           t.bucket_base, bb.queue, t.q_dst, bb.theta, bb.cnt, bb.state, n_groups, s->csr.n_txps);
         OEM_HIP(hipGetLastError());
     }
     return OEM_OK;
@@ -752,18 +801,16 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 {
     // the sweep moves kB times the bytes of k_reldiff_swap_clear: 256 workgroups (97 -> ~30 us at 200 k transcripts)
     const int grid = grid_for(p.n_txps, kRelB, 256);
-    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, bb.stream, bb.theta, bb.cnt, bb.cnt2, bb.out,
-                       bb.state, p);
+    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, bb.stream, bb.theta, bb.cnt, bb.out, bb.state, p);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }
 
 int launch_batch_reset_slot(oem_store *s, const BatchBuffers &bb, const double *d_init, double avg, uint32_t slot)
 {
-    // the slot's queue plane: entries of reads its new resample does not draw are never written again
-    OEM_HIP(hipMemsetAsync(bb.queue + (size_t)slot * s->tiled.n_remote, 0, sizeof(double) * (size_t)s->tiled.n_remote, bb.stream));
+    // (the queue needs no reset: every pass writes every entry of every slot, zeros for the reads a resample did not draw)
     const int grid = grid_for(s->csr.n_txps, 256, 256);
-    hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, bb.stream, bb.theta, bb.cnt, bb.cnt2, d_init, avg,
+    hipLaunchKernelGGL(k_reset_slot_b, dim3(grid), dim3(256), 0, bb.stream, bb.theta, bb.cnt, d_init, avg,
                        s->csr.n_txps, slot);
     OEM_HIP(hipGetLastError());
     return OEM_OK;

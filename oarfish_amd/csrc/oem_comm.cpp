@@ -123,6 +123,9 @@ int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStr
 int p2p_reldiff(P2P *p, double *prev, double *curr, EmState *state, EmParams prm, hipStream_t st);
 int p2p_check(P2P *p, hipStream_t st);
 void p2p_set_shape(P2P *p, int shape);
+int p2p_set_timeout_ms(P2P *p, uint64_t ms);
+void p2p_set_self_check(P2P *p, bool on);
+bool p2p_fine_grained(const P2P *p);
 
 // Vectors up to this size take the peer-to-peer exchange when it is connected (latency-bound: every
 // rank reads N - 1 partials over its own links at once); larger ones (the batched bootstrap's
@@ -134,6 +137,8 @@ struct Comm {
     P2P *p2p = nullptr;
     size_t p2p_max_bytes = kP2PMaxBytes; // OEM_COMM_OPT_P2P_MAX_BYTES (0: RCCL only)
     int p2p_shape = 0;                   // OEM_COMM_OPT_P2P_SHAPE (kept here too: it may be set before the export)
+    uint64_t p2p_timeout_ms = 0;         // OEM_COMM_OPT_P2P_TIMEOUT_MS (0: the default)
+    bool p2p_self_check = false;         // OEM_COMM_OPT_P2P_SELF_CHECK
     int rank = 0;
     int n_ranks = 1;
     int device = 0;
@@ -318,6 +323,8 @@ extern "C" int oem_comm_p2p_export(oem_comm *comm, uint64_t capacity, void *out_
     if (!c || !out_handle || capacity == 0) return fail(OEM_ERR_ARG, "oem_comm_p2p_export: bad argument");
     if (!c->p2p) OEM_TRY(p2p_create(c->rank, c->n_ranks, c->device, &c->p2p));
     p2p_set_shape(c->p2p, c->p2p_shape);
+    p2p_set_self_check(c->p2p, c->p2p_self_check);
+    if (c->p2p_timeout_ms) OEM_TRY(p2p_set_timeout_ms(c->p2p, c->p2p_timeout_ms));
     return p2p_export(c->p2p, capacity, out_handle);
     OEM_API_END("oem_comm_p2p_export")
 }
@@ -343,6 +350,14 @@ extern "C" int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t val
         if (value > 2) return fail(OEM_ERR_ARG, "oem_comm_set_option: peer-to-peer shape is 0 (by rank count), 1 (one-shot) or 2 (two-phase)");
         c->p2p_shape = (int)value;
         p2p_set_shape(c->p2p, c->p2p_shape);
+        return OEM_OK;
+    case OEM_COMM_OPT_P2P_TIMEOUT_MS:
+        if (value == 0 || value > 3600000) return fail(OEM_ERR_ARG, "oem_comm_set_option: timeout of 1 .. 3 600 000 ms");
+        c->p2p_timeout_ms = value;
+        return p2p_set_timeout_ms(c->p2p, value);
+    case OEM_COMM_OPT_P2P_SELF_CHECK:
+        c->p2p_self_check = value != 0;
+        p2p_set_self_check(c->p2p, c->p2p_self_check);
         return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_comm_set_option: unknown option %u", option);
     }

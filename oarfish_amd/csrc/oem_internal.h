@@ -125,8 +125,9 @@ struct DeviceTiled {
     // dictionary-coded local weights (oem_layout_dict.hip), when the store has at most 256 distinct ones
     uint32_t dict_n = 0;           // entries of the table (0: not coded, the kernels read w32)
     bool dict_fused = false;       // <= 128 entries: the index sits in the spare bits of the window codes, no widx
-    float *dict = nullptr;         // 256 floats, ascending, [0] = 0.0
-    uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles
+    bool dict_words = false;       // 257 .. 1024 entries: 16-bit indices, two per word, in the geometry of the codes
+    float *dict = nullptr;         // 1024 floats, ascending, [0] = 0.0
+    uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles (dict_words: see above)
     uint32_t *i_base = nullptr;    // n_tiles + 1: first index row of each tile
     uint8_t *r_wi = nullptr;       // n_remote: table index of each remote record's weight
 };
@@ -160,10 +161,9 @@ struct BatchBuffers {
     hipStream_t stream = nullptr; // the chain's own stream (chain 0: the store's)
     uint32_t *d_row_w = nullptr;  // n_reads u32: the replicate being handed to a slot, caller order
     double *theta = nullptr;   // [T][kBatch]
-    double *cnt = nullptr;     // [T][kBatch]  (tile-kernel flushes)   } contiguous: one all-reduce
-    double *cnt2 = nullptr;    // [kBatch][T]  (fold-kernel flushes)   }
+    double *cnt = nullptr;     // [T][kBatch]  (flushes of the tile kernel and of the fold)
     double *out = nullptr;     // [kBatch][T]
-    double *queue = nullptr;   // [kBatch][n_remote]
+    double *queue = nullptr;   // [n_remote][kBatch]
     BatchState *state = nullptr;
     uint8_t *row_w = nullptr;  // [rows][kBatch], tile order: one byte per slot
     uint32_t *overflow = nullptr;
@@ -181,6 +181,13 @@ struct MultiBuffers {
     BatchState *h_state = nullptr; // host copy
     double *out = nullptr;         // [n_problems * problem_size]
     uint32_t *n_unfinished = nullptr; // device counter
+    // live work of the batch, compacted by the host's look at the device state (k_multi_compact): the tiles and
+    // the remote buckets of the cells that are still running, in their original order
+    uint32_t *live_tiles = nullptr;   // [n_tiles]
+    uint32_t *live_buckets = nullptr; // [n_buckets]
+    uint32_t *d_live_counts = nullptr; // device: {n_live_tiles, n_live_buckets}
+    uint32_t n_live_tiles = 0, n_live_buckets = 0; // host copies: the grids of the next launches
+    bool live_valid = false;
 };
 
 struct Comm; // oem_comm.cpp
@@ -244,6 +251,7 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
 int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int launch_multi_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
+int multi_compact_live(oem_store *s, MultiBuffers &mb); // rebuilds the live lists (synchronises the stream)
 int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_perm);
 
 // batched bootstrap (oem_batch_kernels.hip)

@@ -41,8 +41,8 @@ constexpr uint32_t kTileRows = 1024;  // reads per tile (16 slices of 64)
 constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB of LDS); 8*kWin must fit 16 bits
 constexpr uint32_t kWinWide = 2048;   // window cap of sparse stores (few reads per transcript: per-cell batches)
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
-constexpr uint32_t kBucket = 8192;    // transcripts per remote bucket (64 KiB of LDS)
-constexpr uint32_t kBucketShift = 13;
+constexpr uint32_t kBucket = 4096;    // transcripts per remote bucket (32 KiB of LDS; x 4 slots = 128 KiB in the batched bootstrap's fold)
+constexpr uint32_t kBucketShift = 12;
 static_assert((1u << kBucketShift) == kBucket, "bucket of a transcript = id >> kBucketShift");
 constexpr uint32_t kPackRowShift = 22; // packed remote record: (transcript - problem base) | read-in-tile << 22
 static_assert((kTileRows - 1) >> (32 - kPackRowShift) == 0, "the read index must fit above the transcript bits");

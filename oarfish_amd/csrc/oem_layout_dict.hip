@@ -11,6 +11,10 @@
 // over -- lossless, no tolerance involved.  Measured at C3 (98 distinct weights): the pass
 // 0.199 -> 0.176 ms (profiles/r03_notes.md): the pass follows its bytes.
 //
+// Round 4: 257 .. 1024 distinct weights (what long reads produce: integer score gaps up to 5 % of a best score in the
+// thousands, and exp(-gap / 5) reaches 0 in f32 at a gap of ~520) take 16-bit indices, two per u32 in the geometry
+// of the window codes (2 + 2 bytes per local alignment), from a 4 KiB table in LDS.
+//
 // Stores with more distinct weights, f64 weights (the coverage model multiplies a second factor in) or the wide
 // window cap (per-cell batches: see build_weight_dictionary) keep the f32 stream; `oem_store_opts.weight_coding = 1` keeps it for any store.
 //
@@ -31,7 +35,8 @@ namespace oem {
 namespace {
 
 constexpr int kDT = 256;
-constexpr uint32_t kSetSlots = 1024; // open addressing, <= 257 live keys
+constexpr uint32_t kDictMax = 1024;  // entries of the largest table (16-bit indices; 4 KiB of LDS in k_em_tile)
+constexpr uint32_t kSetSlots = 4096; // open addressing, <= kDictMax + 1 live keys
 constexpr uint32_t kEmptyKey = 0xffffffffu; // a NaN pattern: never a weight of the store (NaN rows were dropped at upload)
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x)
@@ -140,6 +145,43 @@ __global__ __launch_bounds__(kDT) void k_dict_encode(const TileDesc *__restrict_
     }
 }
 
+// 257 .. kDictMax distinct weights: 16-bit indices, two per u32, in the geometry of the window codes (the index
+// word of alignments 2g, 2g+1 of a lane's read sits where their code word sits: widx16[(c_base + ...) * 64 + lane]),
+// so the kernels address it with the code offsets they already have.  2 + 2 bytes per local alignment.
+__global__ __launch_bounds__(kDT) void k_dict_encode16(const TileDesc *__restrict__ tiles, const float *__restrict__ w,
+                                                       const float *__restrict__ dict, uint32_t n_dict,
+                                                       uint32_t *__restrict__ widx16, uint32_t *bad)
+{
+    __shared__ uint32_t keys[kDictMax];
+    const TileDesc td = tiles[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < kDictMax; i += kDT) keys[i] = i < n_dict ? __float_as_uint(dict[i]) : 0x7f800000u;
+    __syncthreads();
+    uint32_t woff = td.w_base, coff = td.c_base;
+    for (uint32_t s = 0; s < kTileSlices; ++s) {
+        const uint32_t width = td.width[s], pairs = (width + 1u) >> 1;
+        for (uint32_t e = threadIdx.x; e < pairs * 64; e += kDT) {
+            const uint32_t g = e >> 6, lane = e & 63u;
+            uint32_t word = 0;
+            for (uint32_t m = 0; m < 2; ++m) {
+                const uint32_t j = 2 * g + m;
+                if (j >= width) break;
+                const uint32_t key = __float_as_uint(w[(size_t)(woff + j) * 64 + lane]);
+                uint32_t a = 0, b = n_dict;
+                while (a < b) {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (keys[mid] < key) a = mid + 1;
+                    else b = mid;
+                }
+                if (a >= n_dict || keys[a] != key) { *bad = 1u; a = 0; }
+                word |= a << (16 * m);
+            }
+            widx16[(size_t)(coff + g) * 64 + lane] = word;
+        }
+        woff += width;
+        coff += pairs;
+    }
+}
+
 // the remote records' weights -> one table index byte each
 __global__ __launch_bounds__(kDT) void k_dict_encode_remote(const float *__restrict__ r_w, uint64_t n, const float *__restrict__ dict,
                                                             uint32_t n_dict, uint8_t *__restrict__ r_wi, uint32_t *bad)
@@ -162,6 +204,10 @@ __global__ __launch_bounds__(kDT) void k_dict_encode_remote(const float *__restr
 
 // <= 128 distinct weights: the index goes into the spare bits of the alignment's own window code (bits 0..2 and
 // 12..15 of its 16-bit half; the code is 8 * (transcript - lo) < 4096), no index stream
+// kCheckOnly: nothing is written -- the codes are changed in place, so the pass that changes them runs only after
+// this one has found every code and every weight to fit (a store that does not keeps its untouched codes and takes
+// the next coding down)
+template <bool kCheckOnly>
 __global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ tiles, const float *__restrict__ w,
                                                    const float *__restrict__ dict, uint32_t n_dict,
                                                    uint32_t *__restrict__ codes, uint32_t *bad)
@@ -191,7 +237,7 @@ __global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ 
                 if (half & 0xf007u) *bad = 1u; // (a code of the narrow window has these bits clear)
                 word |= ((a & 7u) | ((a & 0x78u) << 9)) << (16 * m);
             }
-            codes[(size_t)(coff + g) * 64 + lane] = word;
+            if (!kCheckOnly) codes[(size_t)(coff + g) * 64 + lane] = word;
         }
         woff += width;
         coff += pairs;
@@ -225,7 +271,7 @@ int build_weight_dictionary(oem_store *s)
         OEM_HIP(hipMalloc((void **)&small, sizeof(uint32_t) * 4));
         OEM_HIP(hipMemsetAsync(gtab, 0xff, sizeof(uint32_t) * kSetSlots, st));
         OEM_HIP(hipMemsetAsync(small, 0, sizeof(uint32_t) * 4, st));
-        const uint32_t limit = 256; // (0.0 is one of them: the SELL padding; a store without padding gets it added below)
+        const uint32_t limit = kDictMax; // (0.0 is one of them: the SELL padding; a store without padding gets it added below)
         uint64_t g = (n + kDT - 1) / kDT;
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(k_dict_collect, dim3((uint32_t)g), dim3(kDT), 0, st, t.w32, n, limit, gtab, small, small + 1);
@@ -241,19 +287,43 @@ int build_weight_dictionary(oem_store *s)
         OEM_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
         OEM_HIP(hipMemcpyAsync(h_tab.data(), gtab, sizeof(uint32_t) * kSetSlots, hipMemcpyDeviceToHost, st));
         OEM_HIP(hipStreamSynchronize(st));
-        if (h_small[1]) return OEM_OK; // more than 256 distinct weights: the f32 stream stays the only one
+        if (h_small[1]) return OEM_OK; // more than kDictMax distinct weights: the f32 stream stays the only one
         std::vector<uint32_t> keys;
         for (uint32_t k : h_tab)
             if (k != kEmptyKey) keys.push_back(k);
         if (std::find(keys.begin(), keys.end(), 0u) == keys.end()) keys.push_back(0u); // index 0 = weight 0.0
         for (uint32_t k : keys)
             if (k & 0x80000000u) return OEM_OK; // a negative (or -0.0) weight: not ordered like its bits; keep f32
-        if (keys.size() > 256) return OEM_OK;
+        if (keys.size() > kDictMax) return OEM_OK;
         std::sort(keys.begin(), keys.end());
-        std::vector<float> dict(256, 0.0f);
+        std::vector<float> dict(kDictMax, 0.0f);
         for (size_t i = 0; i < keys.size(); ++i) std::memcpy(&dict[i], &keys[i], sizeof(float));
-        OEM_HIP(hipMalloc((void **)&t.dict, sizeof(float) * 256));
-        OEM_HIP(hipMemcpyAsync(t.dict, dict.data(), sizeof(float) * 256, hipMemcpyHostToDevice, st));
+        OEM_HIP(hipMalloc((void **)&t.dict, sizeof(float) * kDictMax));
+        OEM_HIP(hipMemcpyAsync(t.dict, dict.data(), sizeof(float) * kDictMax, hipMemcpyHostToDevice, st));
+        if (keys.size() > 256) {
+            // 257 .. 1024 distinct weights (long reads: integer score gaps up to 5 % of a best score in the thousands):
+            // 16-bit indices beside the codes; the remote records keep their f32 weights
+            uint32_t c_rows = last.c_base;
+            for (uint32_t i = 0; i < kTileSlices; ++i) c_rows += (last.width[i] + 1u) >> 1;
+            OEM_HIP(hipMalloc((void **)&t.widx, sizeof(uint32_t) * ((size_t)c_rows + 1) * 64));
+            OEM_HIP(hipMemsetAsync(t.widx + (size_t)c_rows * 64, 0, sizeof(uint32_t) * 64, st));
+            hipLaunchKernelGGL(k_dict_encode16, dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict, (uint32_t)keys.size(),
+                               t.widx, small + 2);
+            OEM_HIP(hipGetLastError());
+            OEM_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
+            OEM_HIP(hipStreamSynchronize(st));
+            if (h_small[2]) { // (cannot happen: every weight was collected) -- the f32 stream stays the only one
+                hipFree(t.widx);
+                hipFree(t.dict);
+                t.widx = nullptr;
+                t.dict = nullptr;
+                return OEM_OK;
+            }
+            s->hbm_bytes += sizeof(uint32_t) * ((size_t)c_rows + 1) * 64 + sizeof(float) * kDictMax;
+            t.dict_words = true;
+            t.dict_n = (uint32_t)keys.size();
+            return OEM_OK;
+        }
         {   // remote records: one index byte instead of the f32 (kept for the batched kernel)
             OEM_HIP(hipMalloc((void **)&t.r_wi, t.n_remote ? t.n_remote : 1));
             s->hbm_bytes += t.n_remote;
@@ -267,15 +337,29 @@ int build_weight_dictionary(oem_store *s)
         }
         if (keys.size() <= 128 && knob("OEM_DICT_NO_FUSE", 0) == 0) { // (knob: testing build, reaches the byte-stream coding)
             // the index fits the spare bits of the window codes: no stream of its own
-            hipLaunchKernelGGL(k_dict_fuse, dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict, (uint32_t)keys.size(),
-                               t.codes, small + 2);
+            // (checked first, written second: a store that does not fit keeps its codes as they are and takes the
+            // byte stream below)
+            hipLaunchKernelGGL((k_dict_fuse<true>), dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict, (uint32_t)keys.size(),
+                               t.codes, small + 3);
             OEM_HIP(hipGetLastError());
             OEM_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, st));
             OEM_HIP(hipStreamSynchronize(st));
-            if (h_small[2]) return fail(OEM_ERR_STATE, "weight dictionary: a window code or a weight did not fit the fused form");
-            t.dict_fused = true;
-            t.dict_n = (uint32_t)keys.size();
-            return OEM_OK;
+            if (!h_small[3] && !h_small[2]) {
+                hipLaunchKernelGGL((k_dict_fuse<false>), dim3(t.n_tiles), dim3(kDT), 0, st, t.tiles, t.w32, t.dict,
+                                   (uint32_t)keys.size(), t.codes, small + 3);
+                OEM_HIP(hipGetLastError());
+                OEM_HIP(hipStreamSynchronize(st));
+                t.dict_fused = true;
+                t.dict_n = (uint32_t)keys.size();
+                return OEM_OK;
+            }
+            if (h_small[2]) { // a remote weight that is not in the table (cannot happen): the f32 stream stays the only one
+                hipFree(t.dict);
+                hipFree(t.r_wi);
+                t.dict = nullptr;
+                t.r_wi = nullptr;
+                return OEM_OK;
+            }
         }
         // per-tile bases of the index words
         OEM_HIP(hipMalloc((void **)&sizes, sizeof(uint32_t) * ((size_t)t.n_tiles + 1)));

@@ -64,12 +64,13 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
                                                             const double *__restrict__ queue,
                                                             const uint16_t *__restrict__ q_dst, double *__restrict__ theta,
                                                             double *__restrict__ cnt, double *__restrict__ out,
-                                                            BatchState *st, uint32_t n_txps, uint32_t T)
+                                                            BatchState *st, uint32_t n_txps, uint32_t T,
+                                                            const uint32_t *__restrict__ live_buckets)
 {
     __shared__ double acc[kBucket];
     __shared__ unsigned long long cmax[kMaxCellsPerBucket];
     __shared__ uint32_t phase_l[kMaxCellsPerBucket];
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = live_buckets ? live_buckets[blockIdx.x] : blockIdx.x;
     const uint32_t t0 = b * kBucket;
     uint32_t t1 = t0 + kBucket - 1;
     if (t1 >= n_txps) t1 = n_txps - 1;
@@ -147,6 +148,47 @@ __global__ __launch_bounds__(kMT) void k_multi_decide(BatchState *st, uint32_t n
 // (em.rs:238-242, the zeroing of small abundances before the final pass, is not a sweep here: k_em_tile reads
 // the abundances of a FINAL cell below the threshold as 0 on the way in.)
 
+// Live-work compaction.  Cells are independent (single_cell.rs:139-160) and stop at their own iteration: half way
+// through the loop most of a batch's tiles belong to finished cells, and launching them only to have their
+// workgroups return costs a fixed ~0.1 ms per pass however few cells are live.  When the host's look at the device
+// state (every 16 passes) finds fewer unfinished cells than at the last compaction, ONE workgroup rewrites the list
+// of live items in their original order (the XCD-aware tile order of k_em_tile works on list positions): item i is
+// live when one of the cells [first(i), last(i)] is not FINISHED.  kTiles: items are tiles (one cell each);
+// otherwise remote buckets (the cells whose transcripts the bucket covers).
+constexpr int kCT = 1024;
+template <bool kTiles>
+__global__ __launch_bounds__(kCT) void k_multi_compact(const TileDesc *__restrict__ tiles, uint32_t n_items,
+                                                       const BatchState *__restrict__ st, uint32_t n_txps, uint32_t T,
+                                                       uint32_t *__restrict__ live, uint32_t *__restrict__ n_live)
+{
+    __shared__ uint32_t part[kCT];
+    const uint32_t per = (n_items + kCT - 1) / kCT;
+    const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < n_items ? i0 + per : n_items;
+    auto is_live = [&](uint32_t i) -> bool {
+        if (kTiles) return st[tiles[i].problem].phase != kPhaseFinished;
+        const uint32_t t0 = i * kBucket;
+        uint32_t t1 = t0 + kBucket - 1;
+        if (t1 >= n_txps) t1 = n_txps - 1;
+        for (uint32_t p = t0 / T; p <= t1 / T; ++p)
+            if (st[p].phase != kPhaseFinished) return true;
+        return false;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += is_live(i) ? 1u : 0u;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < kCT; d <<= 1) { // inclusive scan (Hillis-Steele: 10 steps of one workgroup)
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t o = part[threadIdx.x] - mine;
+    for (uint32_t i = i0; i < i1; ++i)
+        if (is_live(i)) live[o++] = i;
+    if (threadIdx.x == kCT - 1) *n_live = part[kCT - 1];
+}
+
 } // namespace
 
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb)
@@ -165,10 +207,35 @@ int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const Mu
     const DeviceTiled &t = s->tiled;
     const uint32_t T = mb.problem_size;
     const uint32_t gp = (mb.n_problems + kMT - 1) / kMT;
-    hipLaunchKernelGGL(k_multi_fold_reldiff, dim3(t.n_buckets), dim3(kFT), 0, s->stream, t.bucket_base, t.queue, t.q_dst,
-                       theta, cnt, mb.out, mb.state, s->csr.n_txps, T);
+    const uint32_t *live = mb.live_valid ? mb.live_buckets : nullptr;
+    const uint32_t n_b = live ? mb.n_live_buckets : t.n_buckets;
+    if (n_b)
+        hipLaunchKernelGGL(k_multi_fold_reldiff, dim3(n_b), dim3(kFT), 0, s->stream, t.bucket_base, t.queue, t.q_dst,
+                           theta, cnt, mb.out, mb.state, s->csr.n_txps, T, live);
     hipLaunchKernelGGL(k_multi_decide, dim3(gp), dim3(kMT), 0, s->stream, mb.state, mb.n_problems, p, mb.n_unfinished);
     OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int multi_compact_live(oem_store *s, MultiBuffers &mb)
+{
+    const DeviceTiled &t = s->tiled;
+    if (!mb.live_tiles) {
+        OEM_HIP(hipMalloc((void **)&mb.live_tiles, sizeof(uint32_t) * (t.n_tiles ? t.n_tiles : 1)));
+        OEM_HIP(hipMalloc((void **)&mb.live_buckets, sizeof(uint32_t) * (t.n_buckets ? t.n_buckets : 1)));
+        OEM_HIP(hipMalloc((void **)&mb.d_live_counts, sizeof(uint32_t) * 2));
+    }
+    hipLaunchKernelGGL((k_multi_compact<true>), dim3(1), dim3(kCT), 0, s->stream, t.tiles, t.n_tiles, mb.state,
+                       s->csr.n_txps, mb.problem_size, mb.live_tiles, mb.d_live_counts);
+    hipLaunchKernelGGL((k_multi_compact<false>), dim3(1), dim3(kCT), 0, s->stream, t.tiles, t.n_buckets, mb.state,
+                       s->csr.n_txps, mb.problem_size, mb.live_buckets, mb.d_live_counts + 1);
+    OEM_HIP(hipGetLastError());
+    uint32_t h[2] = {0, 0};
+    OEM_HIP(hipMemcpyAsync(h, mb.d_live_counts, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    OEM_HIP(hipStreamSynchronize(s->stream));
+    mb.n_live_tiles = h[0];
+    mb.n_live_buckets = h[1];
+    mb.live_valid = true;
     return OEM_OK;
 }
 

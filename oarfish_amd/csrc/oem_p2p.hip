@@ -39,9 +39,12 @@
 //
 // A spinning wait is bounded (wall clock): a peer that never arrives sets an error flag that the host
 // reports as OEM_ERR_STATE instead of hanging the GPU.
+#include <time.h>
 #include <unistd.h>
 
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "oem_internal.h"
 
@@ -50,7 +53,9 @@ namespace oem {
 constexpr int kP2PMaxRanks = 16;
 constexpr uint32_t kP2PMagic = 0x6f703270u; // "op2p"
 constexpr int kP2PBlock = 256;
-constexpr long long kP2PTimeoutTicks = 8ll * 100000000ll; // wall_clock64() runs at 100 MHz: 8 s
+constexpr long long kP2PTicksPerMs = 100000ll;       // wall_clock64() runs at 100 MHz
+constexpr uint64_t kP2PDefaultTimeoutMs = 8000;       // OEM_COMM_OPT_P2P_TIMEOUT_MS
+constexpr uint64_t kP2PSelfCheckTimeoutMs = 120000;   // the first exchange is also the ranks' rendezvous: wait long
 
 // The region a rank shares with its peers (one allocation, one IPC handle).
 struct P2PShared {
@@ -79,9 +84,10 @@ struct P2PCtl {
     uint32_t arrived_red;
     uint32_t error;           // 1: a peer's flag did not arrive in time
     uint32_t arrived_slice;
-    uint32_t pad[2];
+    long long timeout_ticks;  // bound of one spinning wait (device wall clock)
     P2PShared *peer[kP2PMaxRanks]; // mapped regions, [rank] = own
 };
+static_assert(sizeof(P2PCtl) == 32 + 8 * kP2PMaxRanks, "P2PCtl layout");
 
 struct P2P {
     int rank = 0, n_ranks = 1, device = 0;
@@ -91,6 +97,9 @@ struct P2P {
     P2PCtl *h_ctl = nullptr; // pinned copy for error checks
     void *opened[kP2PMaxRanks] = {};  // hipIpcOpenMemHandle results to close
     bool connected = false;
+    bool fine_grained = false; // the shared region is fine-grained device memory (else ordinary hipMalloc memory)
+    bool self_check = false;   // OEM_COMM_OPT_P2P_SELF_CHECK: oem_comm_p2p_connect ends with a checked exchange
+    uint64_t timeout_ms = kP2PDefaultTimeoutMs;
     int shape = 0; // OEM_COMM_OPT_P2P_SHAPE: 0 by the number of ranks, 1 one-shot, 2 two-phase
 };
 
@@ -99,7 +108,8 @@ struct P2PBlob { // OEM_P2P_HANDLE_BYTES
     uint64_t pid, ptr, capacity;
     int32_t device, rank;
     hipIpcMemHandle_t handle;
-    char pad[OEM_P2P_HANDLE_BYTES - 4 - 4 - 8 - 8 - 8 - 4 - 4 - sizeof(hipIpcMemHandle_t)];
+    uint64_t nonce; // of the exporting PROCESS: ranks in different containers / pid namespaces can share a pid
+    char pad[OEM_P2P_HANDLE_BYTES - 4 - 4 - 8 - 8 - 8 - 4 - 4 - sizeof(hipIpcMemHandle_t) - 8];
 };
 static_assert(sizeof(P2PBlob) == OEM_P2P_HANDLE_BYTES, "P2PBlob size");
 
@@ -130,6 +140,12 @@ __device__ __forceinline__ double sys_load_f64(const double *p)
 }
 // every store this thread has issued is acknowledged by memory
 __device__ __forceinline__ void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The flags are raised with a system-scope RELEASE and consumed with a system-scope ACQUIRE on top of that: only the
+// few threads that raise or wait for a flag execute them (one L2 write-back per exchange and one invalidate per
+// waiting workgroup, not one per wavefront), and the pair is what the memory model asks of a flag that a peer
+// DEVICE polls while this kernel runs -- the by-construction argument above has only ever been run on one device.
+__device__ __forceinline__ void flag_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+__device__ __forceinline__ void flag_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 
 __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restrict__ send, P2PCtl *ctl,
                                                            uint64_t capacity, uint64_t count, int rank, int n_ranks,
@@ -150,8 +166,10 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_publish(const double *__restr
     }
     __syncthreads();
     if (is_last) { // every workgroup's part is in memory: raise this rank's flag at every peer
-        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank)
+        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
+            flag_release();
             sys_store_u64(&ctl->peer[threadIdx.x]->flags[e & 1][rank], e);
+        }
         if (threadIdx.x == 0) ctl->arrived_pub = 0u;
     }
 }
@@ -165,14 +183,15 @@ __device__ __forceinline__ void p2p_wait(P2PCtl *ctl, unsigned long long e, int 
         !__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         P2PShared *self = ctl->peer[rank];
         const unsigned long long *f = flag_b ? &self->flags_b[e & 1][threadIdx.x] : &self->flags[e & 1][threadIdx.x];
-        const long long t0 = wall_clock64();
+        const long long t0 = wall_clock64(), limit = ctl->timeout_ticks;
         while (sys_load_u64(f) < e) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+            if (wall_clock64() - t0 > limit) {
                 ctl->error = 1u;
                 break;
             }
         }
+        flag_acquire();
     }
     __syncthreads();
 }
@@ -250,8 +269,10 @@ __global__ __launch_bounds__(kP2PBlock) void k_p2p_reduce_slice(P2PCtl *ctl, uin
     }
     __syncthreads();
     if (is_last) {
-        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank)
+        if ((int)threadIdx.x < n_ranks && (int)threadIdx.x != rank) {
+            flag_release();
             sys_store_u64(&ctl->peer[threadIdx.x]->flags_b[e & 1][rank], e);
+        }
         if (threadIdx.x == 0) ctl->arrived_slice = 0u;
     }
 }
@@ -346,6 +367,8 @@ __global__ __launch_bounds__(kRB) void k_p2p_reldiff(double *__restrict__ prev, 
             state->niter = niter;
             if (niter >= p.max_iter) state->done = 1;              // em.rs:181
         }
+        // a wait that gave up: the sums of this run are lost -- end it here instead of iterating on stale slots
+        if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) state->done = 1;
         state->rel_bits = 0ull;
         state->blocks_arrived = 0u;
         __hip_atomic_store(&ctl->epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -361,6 +384,31 @@ int grid_for_count(uint64_t n, int block, int max_blocks)
 }
 
 } // namespace
+
+// Identifies this PROCESS among the exporters of a node: the pid alone does not (ranks in separate containers or
+// pid namespaces routinely share one), and a peer mistaken for a thread of this process would have its raw
+// device pointer dereferenced instead of its IPC handle opened.
+static uint64_t process_nonce()
+{
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (f) {
+            if (fread(&v, sizeof(v), 1, f) != 1) v = 0;
+            fclose(f);
+        }
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        v ^= ((uint64_t)ts.tv_sec * 1000000007ull + (uint64_t)ts.tv_nsec) ^ ((uint64_t)(uintptr_t)&nonce << 17) ^ (uint64_t)getpid();
+        return v ? v : 1ull;
+    }();
+    return nonce;
+}
+
+int p2p_self_check(P2P *p);
+int p2p_set_timeout_ms(P2P *p, uint64_t ms);
+int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state);
+int p2p_check(P2P *p, hipStream_t st);
 
 int p2p_create(int rank, int n_ranks, int device, P2P **out)
 {
@@ -397,19 +445,31 @@ int p2p_export(P2P *p, uint64_t capacity, void *out_blob)
     if (p->self) return fail(OEM_ERR_STATE, "oem_comm_p2p_export: already exported");
     OEM_HIP(hipSetDevice(p->device));
     const size_t bytes = sizeof(P2PShared) + 4 * capacity * sizeof(double); // partials and reduced slices, two parities each
-    // Ordinary (cached) device memory: coherence with the peers comes from the system-scope fence before a
-    // flag is raised, the system-scope acquire of the flags and system-scope loads of the peers' partials.
-    // (Uncached memory was tried first: every access then goes to memory one lane at a time -- a 200 k-entry
-    // exchange of ONE rank with itself took 25 us, profiles/r03_notes.md.)
+    // FINE-GRAINED device memory: the region is written by peer devices and polled by this one while kernels
+    // run, which is what fine-grained coherence is specified for (ordinary hipMalloc memory is coarse-grained:
+    // coherent with other agents only at kernel boundaries -- it happened to work with several processes on one
+    // device, where there is one L2 hierarchy, and is kept as the fall-back for a runtime that refuses the flag
+    // or cannot export such an allocation).  Every access is a system-scope access either way (sys_store / sys_load).
+    // (hipDeviceMallocUncached was tried in round 3: every access then goes to memory one lane at a time -- a
+    // 200 k-entry exchange of ONE rank with itself took 25 us, profiles/r03_notes.md.)
     void *mem = nullptr;
     hipIpcMemHandle_t h;
     std::memset(&h, 0, sizeof(h));
-    OEM_HIP(hipMalloc(&mem, bytes));
-    if (p->n_ranks > 1) {
-        hipError_t e = hipIpcGetMemHandle(&h, mem);
-        if (e != hipSuccess) {
-            hipFree(mem);
-            return fail(OEM_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+    p->fine_grained = hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained) == hipSuccess && mem;
+    if (p->fine_grained && p->n_ranks > 1 && hipIpcGetMemHandle(&h, mem) != hipSuccess) {
+        hipFree(mem);
+        mem = nullptr;
+        p->fine_grained = false;
+    }
+    (void)hipGetLastError();
+    if (!p->fine_grained) {
+        OEM_HIP(hipMalloc(&mem, bytes));
+        if (p->n_ranks > 1) {
+            hipError_t e = hipIpcGetMemHandle(&h, mem);
+            if (e != hipSuccess) {
+                hipFree(mem);
+                return fail(OEM_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+            }
         }
     }
     OEM_HIP(hipMemset(mem, 0, bytes));
@@ -429,6 +489,7 @@ int p2p_export(P2P *p, uint64_t capacity, void *out_blob)
     b.device = p->device;
     b.rank = p->rank;
     b.handle = h;
+    b.nonce = process_nonce();
     std::memcpy(out_blob, &b, sizeof(b));
     return OEM_OK;
 }
@@ -451,7 +512,7 @@ int p2p_connect(P2P *p, const void *all_blobs)
                         (unsigned long long)b.capacity, (unsigned long long)p->capacity);
         if (r == p->rank) {
             h.peer[r] = p->self;
-        } else if (b.pid == (uint64_t)getpid()) {
+        } else if (b.pid == (uint64_t)getpid() && b.nonce == process_nonce()) {
             // a rank of this very process (ranks as threads): one address space, no handle to open
             if (b.device != p->device) {
                 int can = 0;
@@ -472,9 +533,73 @@ int p2p_connect(P2P *p, const void *all_blobs)
             h.peer[r] = static_cast<P2PShared *>(m);
         }
     }
+    h.timeout_ticks = (long long)(p->self_check ? kP2PSelfCheckTimeoutMs : p->timeout_ms) * kP2PTicksPerMs;
     OEM_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     p->connected = true;
+    if (p->self_check) {
+        const int rc = p2p_self_check(p);
+        if (rc != OEM_OK) {
+            p->connected = false; // the communicator falls back to RCCL (or reports that it has no backend)
+            return rc;
+        }
+        OEM_TRY(p2p_set_timeout_ms(p, p->timeout_ms));
+    }
     return OEM_OK;
+}
+
+int p2p_set_timeout_ms(P2P *p, uint64_t ms)
+{
+    if (!p) return OEM_OK;
+    if (ms == 0 || ms > 3600000) return fail(OEM_ERR_ARG, "peer-to-peer exchange: timeout of %llu ms (1 .. 3 600 000)", (unsigned long long)ms);
+    p->timeout_ms = ms;
+    if (p->ctl) {
+        OEM_HIP(hipSetDevice(p->device));
+        const long long ticks = (long long)ms * kP2PTicksPerMs;
+        OEM_HIP(hipMemcpy(&p->ctl->timeout_ticks, &ticks, sizeof(ticks), hipMemcpyHostToDevice));
+    }
+    return OEM_OK;
+}
+void p2p_set_self_check(P2P *p, bool on) { if (p) p->self_check = on; }
+bool p2p_fine_grained(const P2P *p) { return p && p->fine_grained; }
+
+// The first exchange, checked: every rank contributes a vector whose sum over the ranks is known in closed form,
+// in both shapes, and compares what it reads back on the host.  It is also the ranks' rendezvous -- the wait of
+// this exchange is long (a peer may still be creating its store), the waits of the EM loop are short.  Run by
+// oem_comm_p2p_connect when OEM_COMM_OPT_P2P_SELF_CHECK is set (every rank is inside connect at the same time when
+// the ranks are processes; ranks that are threads connected one after another by ONE thread must leave it off).
+int p2p_self_check(P2P *p)
+{
+    const uint64_t n = p->capacity < 4096 ? p->capacity : 4096;
+    std::vector<double> h(n);
+    for (uint64_t i = 0; i < n; ++i) h[i] = (double)(p->rank + 1) * 0.5 + (double)(i % 977) * (double)(p->rank + 3);
+    double *d = nullptr;
+    OEM_HIP(hipMalloc((void **)&d, n * sizeof(double)));
+    int rc = OEM_OK;
+    const int saved = p->shape;
+    for (int shape = 1; shape <= 2 && rc == OEM_OK; ++shape) {
+        p->shape = shape;
+        if (hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(OEM_ERR_HIP, "peer-to-peer self check: upload failed"); break; }
+        rc = p2p_allreduce(p, d, d, n, nullptr, nullptr);
+        if (rc != OEM_OK) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = fail(OEM_ERR_HIP, "peer-to-peer self check: the exchange kernels failed"); break; }
+        rc = p2p_check(p, nullptr);
+        if (rc != OEM_OK) break;
+        std::vector<double> got(n);
+        if (hipMemcpy(got.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(OEM_ERR_HIP, "peer-to-peer self check: read-back failed"); break; }
+        const double N = (double)p->n_ranks;
+        for (uint64_t i = 0; i < n; ++i) {
+            // sum over r of (r + 1) / 2 + (i % 977) (r + 3): exact in f64 (small integers and halves)
+            const double want = 0.5 * N * (N + 1.0) / 2.0 + (double)(i % 977) * (N * (N - 1.0) / 2.0 + 3.0 * N);
+            if (got[i] != want) {
+                rc = fail(OEM_ERR_STATE, "peer-to-peer self check (%s): element %llu is %.17g, the sum over %d ranks is %.17g",
+                          shape == 1 ? "one-shot" : "two-phase", (unsigned long long)i, got[i], p->n_ranks, want);
+                break;
+            }
+        }
+    }
+    p->shape = saved;
+    hipFree(d);
+    return rc;
 }
 
 // Two-phase costs one more flag round and one more small kernel (+6 us measured with 3-4 ranks on one device)
@@ -541,7 +666,9 @@ int p2p_check(P2P *p, hipStream_t st)
     if (!p2p_ready(p)) return OEM_OK;
     OEM_HIP(hipMemcpyAsync(p->h_ctl, p->ctl, sizeof(P2PCtl), hipMemcpyDeviceToHost, st));
     OEM_HIP(hipStreamSynchronize(st));
-    if (p->h_ctl->error) return fail(OEM_ERR_STATE, "peer-to-peer exchange: a rank did not arrive within 8 s (rank %d waited)", p->rank);
+    if (p->h_ctl->error)
+        return fail(OEM_ERR_STATE, "peer-to-peer exchange: a rank did not arrive within %.1f s (rank %d waited)",
+                    (double)p->h_ctl->timeout_ticks / (double)(kP2PTicksPerMs * 1000), p->rank);
     return OEM_OK;
 }
 

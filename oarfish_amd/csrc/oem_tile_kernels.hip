@@ -76,14 +76,17 @@ __device__ __forceinline__ double *lds_at(double *base, uint32_t byte_off)
 template <typename WT, int kCh>
 struct SliceRegs {
     WT w[kCh];            // the weights themselves ...
-    uint32_t wi[kCh / 4]; // ... or (dictionary-coded stores, oem_layout_dict.hip) four one-byte table indices per word
+    uint32_t wi[kCh / 2]; // ... or (dictionary-coded stores, oem_layout_dict.hip) table indices: four one-byte ones per
+                          // word (kWBytes: kCh / 4 words) or two 16-bit ones per word (kWWords)
     uint32_t c[kCh / 2];
 };
 // Weight coding of a store (oem_layout_dict.hip): 0 the f32 / f64 stream; 1 one-byte table indices in their own
 // stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
 // (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
-// no weight stream at all, a local alignment is its two code bytes.
-constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2;
+// no weight stream at all, a local alignment is its two code bytes; 3 WORDS: 16-bit indices, two per u32, stored in
+// the geometry of the window codes (257..1024 distinct weights -- long reads with score gaps in the hundreds).
+constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2, kWWords = 3;
+template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 1024 : kDict != kWPlain ? 256 : 1; }
 __device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
 template <int kDict>
 __device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
@@ -94,6 +97,7 @@ template <int kDict, typename WT, int kCh>
 __device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const float *dict_l)
 {
     if (kDict == kWBytes) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
+    if (kDict == kWWords) return (WT)dict_l[code_half(r.wi[k >> 1], k & 1)];
     if (kDict == kWFused) return (WT)dict_l[code_widx(code_half(r.c[k >> 1], k & 1))];
     return r.w[k];
 }
@@ -114,6 +118,8 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
         if ((uint32_t)(2 * g) < width) {
             if (kDict == kWBytes) {
                 if ((g & 1) == 0) r.wi[g >> 1] = ld_stream<kNT>(&ibase[(g >> 1) * 64 + lane]);
+            } else if (kDict == kWWords) {
+                r.wi[g] = ld_stream<kNT>(&ibase[g * 64 + lane]);
             } else if (kDict == kWPlain) {
                 r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
                 r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
@@ -122,6 +128,8 @@ __device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__re
         } else {
             if (kDict == kWBytes) {
                 if ((g & 1) == 0) r.wi[g >> 1] = 0u;
+            } else if (kDict == kWWords) {
+                r.wi[g] = 0u;
             } else if (kDict == kWPlain) {
                 r.w[2 * g] = (WT)0;
                 r.w[2 * g + 1] = (WT)0;
@@ -142,6 +150,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     // weight of alignment j >= kCh of the lane's read (reload loops)
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
         if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
         return (double)wbase[j * 64 + lane];
     };
@@ -153,6 +162,9 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     if (kDict == kWBytes) {
 #pragma unroll
         for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(cur.wi[k]));
+    } else if (kDict == kWWords) {
+#pragma unroll
+        for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.wi[k]));
     } else if (kDict == kWPlain) {
 #pragma unroll
         for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
@@ -254,6 +266,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
 {
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
+        if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
         if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
         return (double)wbase[j * 64 + lane];
     };
@@ -262,6 +275,9 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     if (kDict == kWBytes) {
 #pragma unroll
         for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
+    } else if (kDict == kWWords) {
+#pragma unroll
+        for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
     } else if (kDict == kWPlain) {
 #pragma unroll
         for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
@@ -345,9 +361,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
     const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles,
     const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict,
-    const uint8_t *__restrict__ r_wi)
+    const uint8_t *__restrict__ r_wi, const uint32_t *__restrict__ live_tiles)
 {
-    __shared__ float dict_l[kDict != kWPlain ? 256 : 1]; // the distinct weights of a coded store (oem_layout_dict.hip)
+    __shared__ float dict_l[dict_entries<kDict>()]; // the distinct weights of a coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
@@ -359,10 +375,14 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // cells at a time.  Block b runs on XCD b % 8 (observed placement: a matter of speed only), so block b takes
     // tile (b % 8) * n_tiles / 8 + b / 8: every XCD streams through its own eighth of the cells in order, and the
     // remote gathers hit its L2 instead of fetching a line from memory each (HBM reads of the kernel -45 %).
+    // `live_tiles` (per-cell batch, later in the loop): the tiles of the cells that were unfinished when the host
+    // last compacted the list, in tile order -- n_tiles is then the length of that list, and the grid follows it,
+    // so a pass costs what its live cells cost (oem_multi_kernels.hip: k_multi_compact).
     uint32_t tile_index = blockIdx.x;
     if (problems) {
         tile_index = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
         if (tile_index >= n_tiles) return;
+        if (live_tiles) tile_index = live_tiles[tile_index];
     }
     const TileDesc td = tiles[tile_index]; // one 64-byte scalar load
     const uint32_t ib = kDict == kWBytes ? i_base[tile_index] : 0u; // (requested with it)
@@ -403,8 +423,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             acci += (wi + 3) >> 2;
         }
     }
-    // (a slice's index words, when the weights are dictionary-coded)
-    auto iptr = [&](uint32_t q) -> const uint32_t * { return kDict == kWBytes ? widx + (size_t)ioff[q] * 64 : nullptr; };
+    // (a slice's index words, when the weights are dictionary-coded: byte indices have their own row numbering, 16-bit
+    // ones sit where the slice's code words sit)
+    auto iptr = [&](uint32_t q) -> const uint32_t * {
+        return kDict == kWBytes ? widx + (size_t)ioff[q] * 64 : kDict == kWWords ? widx + (size_t)coff[q] * 64 : nullptr;
+    };
 
     OEM_PROBE(1); // descriptor in hand, slice addresses derived
     // ---- every long-latency load of the tile is issued here, before any use ---------
@@ -420,18 +443,22 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
     }
-    float dict_v = 0.0f;
-    if (kDict != kWPlain && tx < 256) dict_v = dict[tx]; // 1 KiB, L2-resident
+    constexpr uint32_t kDictPer = (dict_entries<kDict>() + kTileThreads - 1) / kTileThreads;
+    float dict_v[kDictPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kDictPer; ++u) // 1 KiB (4 KiB: 16-bit indices), L2-resident
+        dict_v[u] = (kDict != kWPlain && tx + u * kTileThreads < (uint32_t)dict_entries<kDict>()) ? dict[tx + u * kTileThreads] : 0.0f;
     SliceRegs<WT, kCh> R[kSets];
     load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
     // alignments 8..15 of the first slice, into the second set (see fold_first)
     load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
-                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u, kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : nullptr);
+                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u,
+                                    kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : kDict == kWWords ? iptr(0) + (kCh / 2) * 64 : nullptr);
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
     uint32_t rslot[kRem]; // their slot in the bucket-major queue
-    constexpr bool kRemIdx = kDict != kWPlain; // coded stores: a remote record's weight is a table index byte too
+    constexpr bool kRemIdx = kDict == kWBytes || kDict == kWFused; // byte-coded stores: a remote record's weight is a table index byte too
     const uint32_t tid_base = td.problem * problem_size; // first transcript of the tile's EM problem (0: one problem)
     const uint32_t *sd_t = sd + td.sd_begin - td.b_min;  // slot of record i = sd_t[bucket of its transcript] + i
     {
@@ -479,7 +506,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         if (i < td.win_len) theta_l[i] = th(tw[u]);
     }
-    if (kDict != kWPlain && tx < 256) dict_l[tx] = dict_v;
+    if (kDict != kWPlain) {
+#pragma unroll
+        for (uint32_t u = 0; u < kDictPer; ++u)
+            if (tx + u * kTileThreads < (uint32_t)dict_entries<kDict>()) dict_l[tx + u * kTileThreads] = dict_v[u];
+    }
     for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
@@ -623,15 +654,19 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
 {
     const DeviceTiled &t = s->tiled;
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
-    const uint32_t grid = problems ? (t.n_tiles + 7u) / 8u * 8u : t.n_tiles; // (per-cell batch: see the tile index in k_em_tile)
+    // per-cell batch: the compacted list of live tiles once the host has built one (oem_multi_kernels.hip)
+    const uint32_t *live_tiles = problems && s->multi.live_valid ? s->multi.live_tiles : nullptr;
+    const uint32_t n_tiles = live_tiles ? s->multi.n_live_tiles : t.n_tiles;
+    if (n_tiles == 0) return;
+    const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict, t.r_wi);
+                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
     else
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, t.n_tiles, t.widx, t.i_base, t.dict, t.r_wi);
+                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)
@@ -666,10 +701,14 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     } while (0)
     // (a store whose codes carry the fused index has no other way to be read; the knob -- testing build, A/B --
     // switches only the byte-stream coding off)
-    const bool bytes = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
+    const bool coded = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
+    const bool bytes = coded && !t.dict_words, words = coded && t.dict_words;
     if (f64w) {
         if (nt) OEM_TILE(double, true, t.w64, t.r_w64, kWPlain);
         else OEM_TILE(double, false, t.w64, t.r_w64, kWPlain);
+    } else if (words) {
+        if (nt) OEM_TILE(float, true, t.w32, t.r_w32, kWWords);
+        else OEM_TILE(float, false, t.w32, t.r_w32, kWWords);
     } else if (t.dict_fused) {
         if (nt) OEM_TILE(float, true, t.w32, t.r_w32, kWFused);
         else OEM_TILE(float, false, t.w32, t.r_w32, kWFused);

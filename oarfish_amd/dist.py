@@ -187,7 +187,8 @@ def _gather_bytes(raw: bytes, rank: int, world: int, device: int) -> bytes:
     return b"".join(bytes(t.cpu().tolist()) for t in parts)
 
 
-def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_capacity: int = 0) -> Comm:
+def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_capacity: int = 0,
+                p2p_self_check: bool = True, p2p_timeout_ms: int = 0) -> Comm:
     """Create the native communicator of this rank.
 
     ``backend``: "rccl" (the 128-byte unique id travels over the already-initialised
@@ -196,7 +197,10 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
     "both" (RCCL for large vectors, peer to peer for the count vector; ``comm.p2p`` says whether the
     peer-to-peer side came up on every rank -- if it did not, RCCL serves everything).
     ``p2p_capacity``: doubles per exchange buffer (n_txps, or 2 * n_txps * 4 to cover a row-sharded
-    batched bootstrap)."""
+    batched bootstrap).  ``p2p_self_check``: connecting ends with a checked exchange in both shapes against a
+    closed-form sum (OEM_COMM_OPT_P2P_SELF_CHECK) -- a rank whose check fails takes the whole communicator to
+    RCCL ("both") or raises ("p2p"); ``comm.p2p_error`` then carries the first failing rank's message on every
+    rank.  ``p2p_timeout_ms``: bound of one wait inside an exchange kernel (0 = the library's 8 s)."""
     import torch
     import torch.distributed as dist
     if backend not in ("rccl", "p2p", "both"):
@@ -222,6 +226,10 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
         if p2p_capacity <= 0:
             raise ValueError("p2p_capacity (doubles per exchange buffer) is required for the peer-to-peer backend")
         blob = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+        if p2p_self_check and world > 1:   # (ranks are processes here: all of them are inside connect together)
+            _lib.check(L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_SELF_CHECK, 1))
+        if p2p_timeout_ms:
+            _lib.check(L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_TIMEOUT_MS, int(p2p_timeout_ms)))
         rc = L.oem_comm_p2p_export(h, int(p2p_capacity), C.addressof(blob))
         err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
         # every rank must take the same road: connect only if every rank exported
@@ -232,6 +240,11 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
             err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
             oks = _gather_bytes(bytes([1 if rc == _lib.OEM_OK else 0]), rank, world, device)
         comm.p2p = bool(all(oks))
+        if not comm.p2p:   # the first failing rank's message, on every rank (the parsed bench line shows why RCCL carried the run)
+            raw = (f"rank {rank}: {err}" if err else "").encode("utf-8", "replace")[:240].ljust(240, b"\0")
+            allerr = _gather_bytes(raw, rank, world, device)
+            msgs = [allerr[i * 240:(i + 1) * 240].rstrip(b"\0").decode("utf-8", "replace") for i in range(world)]
+            err = next((m for m in msgs if m), err)
         comm.p2p_error = err
         if not comm.p2p:
             if backend == "p2p":

@@ -69,7 +69,7 @@ def _genes(n_txps: int, rng: np.random.Generator):
 
 
 def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_size, gene_of,
-           coverage: bool):
+           coverage: bool, gaps: str = "geometric"):
     rng = np.random.default_rng([seed, c])
     # primary transcript ~ Categorical(a)
     t0 = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int64)
@@ -103,9 +103,18 @@ def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_
     t = np.where(is_gene, in_gene, anywhere)
     t[is_primary] = t0
     # score deficits d (best - s): 0 for the primary, truncated geometric otherwise
-    best = rng.integers(500, 3001, size=n)
-    dmax = np.floor(0.05 * best).astype(np.int64)[row]
-    d = np.minimum(rng.geometric(0.15, size=tot) - 1, dmax)
+    if gaps == "uniform":
+        # Long reads: a best score anywhere in [500, 20 000] and the other alignments' deficits UNIFORM on everything
+        # the reference's score_threshold of 0.95 lets through (oarfish_types.rs:1107-1118) -- up to 1000 distinct
+        # integer gaps, of which exp(-gap / 5) keeps ~520 apart in f32 before it reaches 0: the store with more than
+        # 256 distinct weights that the byte-coded weight table cannot take (oem_layout_dict.hip: 16-bit indices).
+        best = rng.integers(500, 20001, size=n)
+        dmax = np.floor(0.05 * best).astype(np.int64)[row]
+        d = np.floor(rng.random(tot) * (dmax + 1)).astype(np.int64)
+    else:
+        best = rng.integers(500, 3001, size=n)
+        dmax = np.floor(0.05 * best).astype(np.int64)[row]
+        d = np.minimum(rng.geometric(0.15, size=tot) - 1, dmax)
     d[is_primary] = 0
     # distinct targets per read: keep the smallest deficit of each (row, tid)
     order = np.lexsort((d, t, row))
@@ -125,7 +134,12 @@ def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_
 
 
 def make_store(n_reads: int, n_txps: int, kbar: float = 8.0, seed: int = BASE_SEED,
-               coverage: bool = False, threads: int = 8) -> SyntheticStore:
+               coverage: bool = False, threads: int = 8, gaps: str = "geometric") -> SyntheticStore:
+    """``gaps``: "geometric" (score deficits Geom(0.15), best score 500..3000 -- ~100 distinct
+    weights) or "uniform" (long reads: deficits uniform on [0, 0.05 best], best score 500..20 000 -- ~520 distinct
+    weights; see _chunk)."""
+    if gaps not in ("geometric", "uniform"):
+        raise ValueError("gaps must be 'geometric' or 'uniform'")
     rng0 = np.random.default_rng([seed, 0xA11CE])
     a = rng0.lognormal(0.0, 2.0, size=n_txps)
     a /= a.sum()
@@ -136,7 +150,7 @@ def make_store(n_reads: int, n_txps: int, kbar: float = 8.0, seed: int = BASE_SE
     sizes = [min(CHUNK, n_reads - c * CHUNK) for c in range(n_chunks)]
 
     def run(c):
-        return _chunk(c, sizes[c], seed, n_txps, kbar, cdf, g_start, g_size, gene_of, coverage)
+        return _chunk(c, sizes[c], seed, n_txps, kbar, cdf, g_start, g_size, gene_of, coverage, gaps)
 
     if n_chunks > 1 and threads > 1:
         with ThreadPoolExecutor(max_workers=threads) as ex:

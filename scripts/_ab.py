@@ -1,0 +1,50 @@
+"""A/B helper for the measurement scripts: OEM_AB_DIR=<dir> makes them load liboarfish_em*.so from <dir> (a
+snapshot of an earlier build, e.g. oarfish_amd/ab_base/) instead of the in-tree libraries, so that two builds
+can be timed side by side in ONE gpurun call on one box.  Only scripts/ import this; the package itself never
+looks at the variable."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oarfish_amd import _lib  # noqa: E402
+
+_d = os.environ.get("OEM_AB_DIR")
+if _d:
+    _d = os.path.abspath(_d)
+    _lib.LIB_PATH = os.path.join(_d, "liboarfish_em.so")
+    _lib.TESTING_LIB_PATH = os.path.join(_d, "liboarfish_em_testing.so")
+    print(f"[ab] libraries from {_d}", file=sys.stderr)
+
+
+# The synthetic stores take longer to generate than to measure (C3: ~30 s on the box's 16 CPUs): the scripts of
+# one gpurun call share them through /tmp (keyed by the generator's arguments).
+def _cached_make_store():
+    import hashlib
+    import numpy as np
+    from oarfish_amd import synth
+    orig = synth.make_store
+
+    def make_store(n_reads, n_txps, kbar=8.0, seed=synth.BASE_SEED, coverage=False, threads=8, **kw):
+        if n_reads < 500_000 or os.environ.get("OEM_NO_SYNTH_CACHE"):
+            return orig(n_reads, n_txps, kbar, seed=seed, coverage=coverage, threads=threads, **kw)
+        src = open(synth.__file__, "rb").read()
+        key = hashlib.sha1(repr((n_reads, n_txps, kbar, seed, coverage, sorted(kw.items()))).encode() + src).hexdigest()[:16]
+        d = os.path.join(os.environ.get("OEM_SYNTH_CACHE", "/tmp/oem_synth_cache"), key)
+        names = ["row_ptr", "tid", "as_prob", "cov_prob", "abundance", "gene_of"]
+        if os.path.exists(os.path.join(d, "done")):
+            arrs = [np.load(os.path.join(d, n + ".npy")) if os.path.exists(os.path.join(d, n + ".npy")) else None for n in names]
+            return synth.SyntheticStore(arrs[0], arrs[1], arrs[2], arrs[3], n_txps, arrs[4], arrs[5])
+        st = orig(n_reads, n_txps, kbar, seed=seed, coverage=coverage, threads=max(threads, min(32, os.cpu_count() or 8)), **kw)
+        try:
+            os.makedirs(d, exist_ok=True)
+            for n, a in zip(names, [st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.abundance, st.gene_of]):
+                if a is not None:
+                    np.save(os.path.join(d, n + ".npy"), a)
+            open(os.path.join(d, "done"), "w").close()
+        except OSError:
+            pass
+        return st
+    synth.make_store = make_store
+
+
+_cached_make_store()

@@ -2,6 +2,7 @@
 """Times the batched bootstrap on a C3-shaped store: per batched pass (HIP events) and end to end."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _ab  # noqa: E401,E402,F401  (OEM_AB_DIR: A/B against a snapshot build)
 import numpy as np
 from oarfish_amd import synth, _lib
 from oarfish_amd.types import DeviceStore

@@ -2,6 +2,7 @@
 """A few batched bootstrap passes on a C3-shaped store (profiling target).  usage: boot_passes.py [c3|c2] [n] [cov]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _ab  # noqa: E401,E402,F401  (OEM_AB_DIR: A/B against a snapshot build)
 from oarfish_amd import synth, _lib
 from oarfish_amd.types import DeviceStore
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"

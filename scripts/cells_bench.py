@@ -3,6 +3,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _ab  # noqa: E401,E402,F401  (OEM_AB_DIR: A/B against a snapshot build)
 import oarfish_amd
 from oarfish_amd import synth
 n_cells, rpc, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -6,13 +6,23 @@ usage: hbm_traffic_json.py <collect dir> <workload> <out.json> <tag> [boot|cells
   (boot: the kernels of the batched bootstrap pass, collected on scripts/boot_passes.py;
    cells: the per-cell loop of scripts/cells_bench.py -- per-launch means AND totals over the loop's launches,
    since the traffic of a pass falls as cells finish)"""
-import collections, csv, json, re, sys
+import collections, csv, hashlib, json, os, re, sys
 
 root, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
 KNOWN_KB = 1.5 * 1024 * 1024  # scripts/microbench/stream reads 1.5 GiB per launch
 
 
 COUNTS = {}
+
+
+def kernel_source_sha():
+    """The kernel sources the counters were collected on (bench.py compares it with the tree it runs in)."""
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_layout.h"):
+        with open(os.path.join(root_dir, "oarfish_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def means(path):
@@ -42,13 +52,14 @@ for k in names:
 if cells:
     n = COUNTS[f"{root}/pf/{tag[0]}_counter_collection.csv"]
     doc = {"workload": wl, "command": "python scripts/cells_bench.py 625 50000 60000",
-           "fetch_factor": factor, "per_launch_mean_bytes": kern, "launches": {k: n[k] for k in names},
+           "kernel_source_sha": kernel_source_sha(), "fetch_factor": factor, "per_launch_mean_bytes": kern, "launches": {k: n[k] for k in names},
            "loop_total_bytes": sum((kern[k]["read"] + kern[k]["write"]) * n[k] for k in names)}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc))
     sys.exit(0)
 doc = {
     "workload": wl,
+    "kernel_source_sha": kernel_source_sha(),
     "command": (f"python scripts/boot_passes.py {wl} 20  (4-slot batched passes, all slots running, one chain)" if boot else
                 f"python bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu-baseline --no-f32-compare --bootstraps 0 --cells 0"),
     "fetch_calibration": {

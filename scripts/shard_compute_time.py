@@ -4,6 +4,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _ab  # noqa: E401,E402,F401  (OEM_AB_DIR: A/B against a snapshot build)
 from oarfish_amd import synth
 from oarfish_amd.types import DeviceStore
 full = synth.make_store(10_000_000, 200_000, 8.0, threads=32)

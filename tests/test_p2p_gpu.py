@@ -180,3 +180,38 @@ def test_a_peer_that_never_arrives_is_an_error_not_a_hang():
     finally:
         for h in comms:
             L.oem_comm_destroy(h)
+
+
+@pytest.mark.timeout(120)
+def test_a_peer_that_never_arrives_fails_the_row_sharded_bootstrap_too():
+    """The batched bootstrap of a row shard exchanges through the same communicator (its agreement flags and the
+    per-pass sums of the four slots' counts): a peer that never arrives must surface as OEM_ERR_STATE from
+    oem_bootstrap -- not as OEM_OK with replicates summed from stale exchange slots."""
+    import time
+    L = _lib.lib()
+    comms = []
+    for r in range(2):
+        h = C.c_void_p()
+        _lib.check(L.oem_comm_create(None, r, 2, 0, C.byref(h)))
+        comms.append(h)
+    try:
+        blobs = bytearray()
+        for r in range(2):
+            b = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
+            _lib.check(L.oem_comm_p2p_export(comms[r], 8 * 400, C.addressof(b)))
+            blobs += bytes(b)
+        for r in range(2):
+            _lib.check(L.oem_comm_p2p_connect(comms[r], bytes(blobs)))
+        st = synth.make_store(6_000, 400, seed=8)
+        sh = odist.shard_rows_by_nnz(st.row_ptr, st.tid, st.as_prob, None, 0, 2)
+        with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, st.n_txps) as d:
+            d.attach_comm(comms[0], st.n_reads, sh.row_begin)
+            t = time.perf_counter()
+            with pytest.raises(_lib.OemError) as ei:
+                d.bootstrap(3, seed=5, max_iter=100, conv_thresh=1e-3)
+            dt = time.perf_counter() - t
+            assert ei.value.code == _lib.OEM_ERR_STATE and "did not arrive" in str(ei.value)
+            assert dt < 60.0, dt
+    finally:
+        for h in comms:
+            L.oem_comm_destroy(h)
