@@ -51,8 +51,14 @@ __device__ unsigned long long *g_tile_e_probe = nullptr;
     do {                                                                                                          \
         if (g_tile_e_probe && threadIdx.x == 0) g_tile_e_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
+// cost attribution (test-only library, OEM_TILE_EXP): parts of the kernel switched off -- the results are wrong, the
+// time says what the part costs.  1 queue stores, 2 remote denominator atomics, 4 local scatter atomics,
+// 8 local theta reads of the denominators, 16 remote theta gathers
+__device__ unsigned int g_tile_e_exp = 0;
+#define OEM_EXP_E(bit) ((exp_mask & (bit)) != 0u)
 #else
 #define OEM_PROBE_E(i) do { } while (0)
+#define OEM_EXP_E(bit) false
 #endif
 
 constexpr int kB = kBatch;
@@ -154,7 +160,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
                                              const uint32_t *__restrict__ cbase, const double *theta_l, double *cnt_l,
                                              double *den_l, const uint32_t (&rot8)[kEB], uint32_t act_e, bool load_next,
                                              const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c,
-                                             uint32_t next_width)
+                                             uint32_t next_width, uint32_t exp_mask)
 {
     constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
     // Every use of the slice's registers stays below this point: without the pins the compiler hoists the
@@ -172,12 +178,14 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
     double denom[kEB];
 #pragma unroll
     for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
+    // (cost attribution, test-only library: every lane reads a fixed word of its own instead of its window entry)
+    auto at = [&](uint32_t off, int j) -> uint32_t { return OEM_EXP_E(8u) ? lane * 8u : off + rot8[j]; };
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
         const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : (double)lo.w[k];
 #pragma unroll
-        for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;   // em.rs:111
+        for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;   // em.rs:111
         if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
     }
     if (kHasHi && width > (uint32_t)kBCh) { // wave-uniform
@@ -186,7 +194,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
             const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
             const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : (double)hi.w[k];
 #pragma unroll
-            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off + rot8[j]) * wk;
+            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;
             if (k & 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -198,7 +206,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
         for (int m = 0; m < 4; ++m) {
             const double wk = (double)wv[m];
 #pragma unroll
-            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, off4[m] + rot8[j]) * wk;
+            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off4[m], j)) * wk;
         }
     }
     double inv[kEB];
@@ -221,7 +229,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
                 const double v = wk * inv[j]; // (theta is multiplied in when the window is flushed)
-                if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
+                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -237,7 +245,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
                 for (int j = 0; j < kEB; ++j) {
                     const double v = wk * inv[j];
-                    if (v != 0.0) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
+                    if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +261,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
                 const double v = wk * inv[j];
-                if (v != 0.0) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
+                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
             }
         }
     }
@@ -299,6 +307,11 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     }
     if (!act) return;
     OEM_PROBE_E(0);
+#ifdef OEM_TESTING
+    const uint32_t exp_mask = g_tile_e_exp; // (read once: an SGPR)
+#else
+    constexpr uint32_t exp_mask = 0u;
+#endif
 
     __shared__ double theta_l[kWin * kEB];
     __shared__ double cnt_l[kWin * kEB];
@@ -423,13 +436,16 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
         for (int k = 0; k < kRemE; ++k)
             if (tx + k * kTileThreadsE >= td.remote_cnt) rmult[k] = 0u;
-        // remote alignments: x[b] = theta[t][b] * w; the epoch's four slots are one 32-byte piece
+        // remote alignments: theta[t][b] of the epoch's four slots is one 32-byte piece.  The gathers go out here and
+        // are not looked at before phase A: the theta window is written and the windows are cleared while they are
+        // in flight.  (Measured and dropped, profiles/r04_notes.md: the first slice's local denominators summed in
+        // that shadow too, and dead (read, slot) pairs reading a conflict-free word of their own: +1 % and +2 %.)
         double rx[kRemE][kEB];
 #pragma unroll
         for (int k = 0; k < kRemE; ++k) {
             const double *tp = theta + (size_t)rt[k] * kB + eoff;
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) rx[k][b] = th(tp[b], b) * (double)rw[k];
+            for (int b = 0; b < kEB; ++b) rx[k][b] = OEM_EXP_E(16u) ? 1.0 : tp[b];
         }
         if (kE == 1) {
 #pragma unroll
@@ -454,9 +470,10 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
         for (int k = 0; k < kRemE; ++k)
             if (rmult[k]) {
+                const double wv = (double)rw[k];
 #pragma unroll
                 for (int b = 0; b < kEB; ++b)
-                    if ((rmult[k] >> (8 * b)) & 0xffu) lds_add(&den_l[b * kTileRows + rrow[k]], rx[k][b]);
+                    if (((rmult[k] >> (8 * b)) & 0xffu) && !OEM_EXP_E(2u)) lds_add(&den_l[b * kTileRows + rrow[k]], th(rx[k][b], b) * wv);
             }
         for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // beyond the register-resident records
             const uint32_t o = td.remote_begin + i;
@@ -477,14 +494,14 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             if (s0 < td.n_slices)
                 fold_slice_e<WT, kNT, true>(R[0], R[1], wid[0], mult[0], s0 * 64 + lane, lane, w + (size_t)woff[0] * 64,
                                             codes + (size_t)coff[0] * 64, theta_l, cnt_l, den_l, rot8, act_e, true,
-                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1]);
+                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1], exp_mask);
             else
                 load_slice_b<kNT, WT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
             OEM_PROBE_E(6);
             if (s1 < td.n_slices)
                 fold_slice_e<WT, kNT, false>(R[0], R[0], wid[1], mult[1], s1 * 64 + lane, lane, w + (size_t)woff[1] * 64,
                                              codes + (size_t)coff[1] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
-                                             nullptr, nullptr, 0u);
+                                             nullptr, nullptr, 0u, exp_mask);
             OEM_PROBE_E(7);
         } else {
 #pragma unroll 1
@@ -508,7 +525,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                     }
                 fold_slice_e<WT, kNT, false>(cur, cur, width, mq, s * 64 + lane, lane, w + (size_t)wo * 64,
                                              codes + (size_t)co * 64, theta_l, cnt_l, den_l, rot8, act_e, false, nullptr,
-                                             nullptr, 0u);
+                                             nullptr, 0u, exp_mask);
             }
         }
         __syncthreads();
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // ---- remote phase B: queue[record][.] <- w * (c_ib / denom_ib), the epoch's slots as one 32-byte piece ----
 #pragma unroll
         for (int k = 0; k < kRemE; ++k) {
-            if (tx + k * kTileThreadsE < td.remote_cnt) {
+            if (tx + k * kTileThreadsE < td.remote_cnt && !OEM_EXP_E(1u)) {
                 double *qp = queue + (size_t)rslot[k] * kB + eoff;
                 const double wv = (double)rw[k];
                 double qv[kEB];
@@ -583,27 +600,45 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
     struct alignas(16) D2 { double x, y; };
     const D2 *q2 = reinterpret_cast<const D2 *>(queue);
     auto piece = [&](uint32_t o) -> const D2 * { return q2 + ((size_t)o * kB + s_first) / 2 + half; };
-    uint32_t o = s0 + (threadIdx.x >> 1);
-    for (; o + (kFoldDepth - 1) * kEntriesPerStep < s1; o += kFoldDepth * kEntriesPerStep) {
-        D2 v[kFoldDepth];
-        uint32_t d[kFoldDepth];
+    // Two register sets: the loads of the next step are in flight while this step's values go into the LDS window
+    // (one 16-wavefront workgroup per CU: nothing else on the CU hides a wave's round trip).  Entries past the
+    // range are clamped to its last one and skipped at the point of use.
+    constexpr uint32_t kStep = kFoldDepth * kEntriesPerStep;
+    auto load = [&](D2 (&v)[kFoldDepth], uint32_t (&d)[kFoldDepth], uint32_t o) {
 #pragma unroll
         for (int k = 0; k < kFoldDepth; ++k) {
-            v[k] = *piece(o + k * kEntriesPerStep);
-            d[k] = q_dst[o + k * kEntriesPerStep];
+            const uint32_t oo = o + k * kEntriesPerStep, oc = oo < s1 ? oo : s1 - 1;
+            v[k] = *piece(oc);
+            d[k] = q_dst[oc];
         }
+    };
+    auto consume = [&](const D2 (&v)[kFoldDepth], const uint32_t (&d)[kFoldDepth], uint32_t o) {
 #pragma unroll
         for (int k = 0; k < kFoldDepth; ++k) {
-            double *a = &acc[d[k] * kFS + 2 * half];
-            if (v[k].x != 0.0) lds_add(a, v[k].x);
-            if (v[k].y != 0.0) lds_add(a + 1, v[k].y);
+            if (o + k * kEntriesPerStep < s1) {
+                double *a = &acc[d[k] * kFS + 2 * half];
+                if (v[k].x != 0.0) lds_add(a, v[k].x);
+                if (v[k].y != 0.0) lds_add(a + 1, v[k].y);
+            }
         }
-    }
-    for (; o < s1; o += kEntriesPerStep) {
-        const D2 v = *piece(o);
-        double *a = &acc[(uint32_t)q_dst[o] * kFS + 2 * half];
-        if (v.x != 0.0) lds_add(a, v.x);
-        if (v.y != 0.0) lds_add(a + 1, v.y);
+    };
+    D2 va[kFoldDepth], vb[kFoldDepth];
+    uint32_t da[kFoldDepth], db[kFoldDepth];
+    const uint32_t lane_off = threadIdx.x >> 1;
+    uint32_t qb = s0; // (uniform: every thread of the workgroup makes the same trips)
+    load(va, da, qb + lane_off);
+    for (;;) {
+        const uint32_t b1 = qb + kStep;
+        const bool more1 = b1 < s1;
+        if (more1) load(vb, db, b1 + lane_off);
+        consume(va, da, qb + lane_off);
+        if (!more1) break;
+        const uint32_t b2 = b1 + kStep;
+        const bool more2 = b2 < s1;
+        if (more2) load(va, da, b2 + lane_off);
+        consume(vb, db, b1 + lane_off);
+        if (!more2) break;
+        qb = b2;
     }
     __syncthreads();
     // flush: thread i takes window elements i, i + 1024, ...: (transcript, slot) pairs in [t][slot] order -- for
@@ -754,6 +789,16 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
+#ifdef OEM_TESTING
+    {
+        static unsigned int current = 0;
+        const unsigned int want = (unsigned int)knob("OEM_TILE_EXP", 0);
+        if (want != current) {
+            OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_e_exp), &want, sizeof(want)));
+            current = want;
+        }
+    }
+#endif
     const bool f64w = s->csr.w_is_f64;
     const uint64_t wsz = f64w ? 8 : 4;
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));

@@ -31,8 +31,14 @@ __device__ unsigned long long *g_tile_probe = nullptr;
     do {                                                                                                      \
         if (g_tile_probe && threadIdx.x == 0) g_tile_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
+// cost attribution (test-only library, OEM_TILE_EXP): parts of the kernel switched off -- wrong results, the time
+// says what the part costs.  1 queue stores, 2 remote denominator atomics, 4 local scatter atomics, 8 local theta
+// reads, 16 remote theta gathers
+__device__ unsigned int g_tile_exp = 0;
+#define OEM_EXP(bit) ((exp_mask & (bit)) != 0u) // (exp_mask: g_tile_exp read once per kernel, an SGPR)
 #else
 #define OEM_PROBE(i) do { } while (0)
+#define OEM_EXP(bit) false
 #endif
 
 __device__ __forceinline__ void lds_add_f64(double *p, double v)
@@ -84,9 +90,9 @@ struct SliceRegs {
 // stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
 // (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
 // no weight stream at all, a local alignment is its two code bytes; 3 WORDS: 16-bit indices, two per u32, stored in
-// the geometry of the window codes (257..1024 distinct weights -- long reads with score gaps in the hundreds).
+// the geometry of the window codes (257..768 distinct weights -- long reads with score gaps in the hundreds).
 constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2, kWWords = 3;
-template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 1024 : kDict != kWPlain ? 256 : 1; }
+template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 768 : kDict != kWPlain ? 256 : 1; }
 __device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
 template <int kDict>
 __device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
@@ -145,7 +151,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
                                            const double *theta_l, double *cnt_l, double *den_l,
                                            const uint32_t *__restrict__ row_w_perm,
-                                           const uint32_t *__restrict__ ibase, const float *dict_l)
+                                           const uint32_t *__restrict__ ibase, const float *dict_l, uint32_t exp_mask)
 {
     // weight of alignment j >= kCh of the lane's read (reload loops)
     auto w_at = [&](uint32_t j) -> double {
@@ -182,7 +188,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
 #pragma unroll
     for (int k = 0; k < kCh; ++k) {
         const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
-        x[k] = lds_ld(theta_l, off) * (double)wz[k];                       // em.rs:111
+        x[k] = lds_ld(theta_l, OEM_EXP(8u) ? lane * 8u : off) * (double)wz[k]; // em.rs:111
         denom += x[k];
     }
     for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
@@ -219,14 +225,14 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
             const double v = x[k] * inv;
-            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
@@ -262,7 +268,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
                                            const uint32_t *__restrict__ row_w_perm, bool prefetch_next,
                                            const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width,
                                            const uint32_t *__restrict__ ibase, const uint32_t *__restrict__ next_i,
-                                           const float *dict_l)
+                                           const float *dict_l, uint32_t exp_mask)
 {
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
@@ -292,7 +298,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     for (int k = 0; k < kCh; ++k) {
         const WT wk = (kDict == kWPlain && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(lo, k, dict_l);
         const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
-        x[k] = lds_ld(theta_l, off) * (double)wk;                            // em.rs:111
+        x[k] = lds_ld(theta_l, OEM_EXP(8u) ? lane * 8u : off) * (double)wk;      // em.rs:111
         denom += x[k];
     }
     if (width > (uint32_t)kCh) { // wave-uniform
@@ -329,7 +335,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
             const double v = x[k] * inv;
-            if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
         }
     }
     // the first register set is done: the next slice's loads go out now, under the rest of this fold
@@ -340,7 +346,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
             if ((uint32_t)(k + kCh) < width) { // uniform
                 const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
                 const double v = lds_ld(theta_l, off) * (double)slice_w<kDict>(hi, k, dict_l) * inv;
-                if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+                if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
             }
         }
     }
@@ -348,7 +354,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
     }
 }
 
@@ -369,6 +375,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     OEM_PROBE(0);
+#ifdef OEM_TESTING
+    const uint32_t exp_mask = g_tile_exp;
+#else
+    constexpr uint32_t exp_mask = 0u;
+#endif
     // (the descriptor is requested before the run's state is looked at: two scalar loads in flight, not a chain)
     // Per-cell batch: the abundances of ALL cells together (300 MB for 625 cells) fit no cache, those of the cells
     // one XCD is working on do (a cell's 60 k transcripts are 480 KB of its 4 MiB L2) -- if the XCD works on few
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         // (coded: the weight comes from the 1 KiB table in memory -- L1-resident -- in the same round trip as theta)
 #pragma unroll
         for (int k = 0; k < kRem; ++k)
-            rx[k] = th(theta[rt[k]]) * (kRemIdx ? (double)dict[ri[k]] : (double)rw[k]);
+            rx[k] = th(OEM_EXP(16u) ? 1.0 : theta[rt[k]]) * (kRemIdx ? (double)dict[ri[k]] : (double)rw[k]);
         // the slots are wanted last (phase B): a few words per tile, cache-resident.  Branch-free and back to
         // back -- a lookup per branch made the compiler wait for each one in turn, six dependent round trips
         // (a tile without remote records reads the table's slack word)
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // ---- remote alignments, phase A: denominators --------------------------------
 #pragma unroll
     for (int k = 0; k < kRem; ++k)
-        if (tx + k * kTileThreads < td.remote_cnt) lds_add_f64(&den_l[rrow[k]], rx[k]);
+        if (tx + k * kTileThreads < td.remote_cnt && !OEM_EXP(2u)) lds_add_f64(&den_l[rrow[k]], rx[k]);
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) { // overflow: park in the queue
         const uint32_t o = td.remote_begin + i;
         uint32_t t, row;
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         fold_first<WT, kCh, kCopies, kNT, kDict>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
                                                  td, theta_l, cnt_l, den_l, row_w_perm, kPerWave > 1,
                                                  w + (size_t)woff[kPerWave > 1 ? 1 : 0] * 64, codes + (size_t)coff[kPerWave > 1 ? 1 : 0] * 64,
-                                                 wid[kPerWave > 1 ? 1 : 0], iptr(0), iptr(kPerWave > 1 ? 1 : 0), dict_l);
+                                                 wid[kPerWave > 1 ? 1 : 0], iptr(0), iptr(kPerWave > 1 ? 1 : 0), dict_l, exp_mask);
     else if (kPerWave > 1)
         load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1], iptr(1));
     OEM_PROBE(6);
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
                        wid[q + 1], iptr(q + 1 < kPerWave ? q + 1 : q));
         if (s < td.n_slices)
             fold_slice<WT, kCh, kCopies, kDict>(R[(q - 1) % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
-                       theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l);
+                       theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l, exp_mask);
         OEM_PROBE(6 + q); // wave 0's slice q folded (its operands had to land first)
     }
     __syncthreads();
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
     for (int k = 0; k < kRem; ++k) {
         const uint32_t i = tx + k * kTileThreads;
-        if (i < td.remote_cnt) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
+        if (i < td.remote_cnt && !OEM_EXP(1u)) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
     }
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
@@ -688,6 +699,16 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
+#ifdef OEM_TESTING
+    {
+        static unsigned int current = 0;
+        const unsigned int want = (unsigned int)knob("OEM_TILE_EXP", 0);
+        if (want != current) {
+            OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_exp), &want, sizeof(want)));
+            current = want;
+        }
+    }
+#endif
     const bool f64w = s->csr.w_is_f64;
     // matrix bytes one pass streams; beyond the Infinity Cache they are loaded non-temporally
     const uint64_t wsz = f64w ? 8 : 4;

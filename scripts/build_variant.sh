@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds the two libraries with extra -D switches into a side directory (for OEM_AB_DIR=<dir>: two builds timed side
+# by side in one gpurun call), then restores the default build.  usage: build_variant.sh <dir> "<-DX=1 ...>"
+set -e
+dir=$1; defs=$2
+cd "$(dirname "$0")/.."
+rm -f oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
+OEM_EXTRA_DEFS="$defs" python -m oarfish_amd.build > /dev/null 2>&1
+mkdir -p "$dir"; cp oarfish_amd/liboarfish_em.so oarfish_amd/liboarfish_em_testing.so "$dir"/
+rm -f oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
+python -m oarfish_amd.build > /dev/null 2>&1
+echo "built $dir with $defs"
