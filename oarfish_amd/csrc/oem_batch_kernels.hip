@@ -295,8 +295,6 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
     const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
 {
-    // (the descriptor is requested before the slots' states are looked at: scalar loads in flight together)
-    const TileDesc td = tiles[blockIdx.x];
     uint32_t act = 0; // slots that take part in this pass (RUNNING or FINAL)
     uint32_t fin = 0; // slots on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
 #pragma unroll
@@ -326,6 +324,10 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     // slices come in descending width: wavefront w takes slice w and slice 15 - w (the widest with the
     // narrowest), not w and w + 8 -- the tile's barriers wait for the wavefront with the most rows
     auto slice_of = [&](uint32_t q) -> uint32_t { return (q & 1u) ? (q + 1) * kWaves - 1 - wave : q * kWaves + wave; };
+    // (one workgroup per tile.  Persistent workgroups -- 512 of them striding over the tiles, so that a tile's queue
+    // stores and flush atomics drain under the next tile's loads -- were measured at +13 % on the batched pass,
+    // profiles/r04_notes.md: like k_em_tile in round 3, the hardware dispatcher does this better.)
+    const TileDesc td = tiles[blockIdx.x];
     uint32_t woff[kPerWave], coff[kPerWave], wid[kPerWave];
     {
         uint32_t accw = td.w_base, accc = td.c_base;

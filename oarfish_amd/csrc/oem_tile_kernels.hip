@@ -21,6 +21,7 @@ namespace oem {
 namespace {
 
 constexpr int kFoldThreads = 1024;
+constexpr uint32_t kFoldEntriesPerGroup = 2 * kBucket; // queue entries that repay a fold workgroup's window clear + flush
 
 // Phase timestamps of k_em_tile (test-only library): wave 0 of every workgroup stamps the device wall clock
 // (100 MHz) at its phase boundaries into g_tile_probe[tile][16] -- scripts/tile_probe.py turns them into the
@@ -685,10 +686,11 @@ static uint32_t fold_groups(const DeviceTiled &t)
     // ~1 workgroup of 1024 threads per CU in total (each flushes a whole bucket window, so
     // fewer, longer-running workgroups mean fewer flush atomics) ...
     uint32_t n_groups = 256u / (t.n_buckets ? t.n_buckets : 1);
-    // ... but every workgroup clears and flushes a whole 64 KiB window, which only pays for
-    // itself with >= 16 Ki queue entries to fold (1 M-read store: 32 Ki 34.5 us, 16 Ki 33.1 us, 8 Ki 35.6 us per pass)
+    // ... but every workgroup clears and flushes a whole window (32 KiB: 4096 transcripts), which only pays for
+    // itself with a few queue entries per window entry to fold (1 M-read store, 8192-transcript windows: 32 Ki entries
+    // 34.5 us, 16 Ki 33.1 us, 8 Ki 35.6 us per pass; the same two entries per window entry with the 4096 ones)
     const uint64_t per_bucket = t.n_remote / (t.n_buckets ? t.n_buckets : 1) + 1;
-    const uint32_t max_useful = (uint32_t)((per_bucket + 16383) / 16384);
+    const uint32_t max_useful = (uint32_t)((per_bucket + kFoldEntriesPerGroup - 1) / kFoldEntriesPerGroup);
     if (n_groups > max_useful) n_groups = max_useful;
     if (n_groups < 1) n_groups = 1;
     return n_groups;

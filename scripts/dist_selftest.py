@@ -8,6 +8,9 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# before the HIP runtime loads: RCCL's request, and the dmabuf IPC mode hipIpc memory handles need with this driver
+os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch, torch.distributed as dist
 from oarfish_amd import synth, dist as odist
 from oarfish_amd.types import DeviceStore

@@ -90,3 +90,23 @@ def test_bench_two_ranks_on_one_device_over_p2p():
     for name in ("em", "em_par"):   # the sharded loop converges like the un-sharded one (tiny store: a handful of passes)
         assert d["em_to_convergence"][name]["n_passes"] >= 3
     assert d["roofline"] and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_without_the_ipc_variable_in_the_environment():
+    """The driver launches bench.py with whatever environment the node has.  With HSA_ENABLE_IPC_MODE_LEGACY absent
+    bench.py sets it itself (before the HIP runtime loads), so the first multi-GPU run takes the peer-to-peer
+    exchange it was built for instead of silently timing a fall-back; and whatever happens the line appears, with the
+    per-candidate outcome in config.exchange."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "tiny",
+           "--steps", "4", "--warmup", "1", "--bootstraps", "0", "--cells", "0", "--no-cpu-baseline", "--same-device"]
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=800, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    ex = d["config"]["exchange"]
+    assert ex["p2p_connected"], ex                       # the variable was defaulted: hipIpc handles worked
+    assert set(ex["candidate_ok"]) == set(ex["candidates"]) and all(ex["candidate_ok"].values())
+    assert ex["backend"].startswith("p2p") and "p2p_not_used_because" not in ex

@@ -3,11 +3,13 @@ committed golden fixtures.  Tolerance: BASELINE.json north_star -- abundances
 within 1e-4 relative of the reference algorithm (f64 arithmetic; the only
 difference allowed is floating-point summation order, so the observed error is
 ~1e-12 and most checks are far tighter than 1e-4)."""
+import os
+
 import numpy as np
 import pytest
 
 import oarfish_amd
-from oarfish_amd import synth
+from oarfish_amd import _lib, synth
 from oarfish_amd.types import DeviceStore, InMemoryAlignmentStore
 from oracle import c_oracle
 from tests.common import assert_counts_close, golden_names, load_golden
@@ -858,6 +860,63 @@ def test_full_size_c3_to_convergence_matches_oracle_under_both_gates():
         assert_counts_close(cnt, want, st.n_reads, st.n_txps, RTOL if info.niter != wi.niter else 1e-8,
                             f"c3 to convergence, gate {gate}")
         assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads
+
+
+@pytest.mark.timeout(900)
+def test_full_size_c3_coverage_store_matches_oracle():
+    """The C3-sized store WITH the coverage column (--model-coverage, the authors' recommended mode: f64 weights
+    w = (f64)as_prob * cov_prob, em.rs:107-111; 12 bytes per alignment, the f64 instantiations of both tile kernels):
+    12 iterations against the multi-threaded oracle on every transcript, then to convergence with the invariants --
+    and two batched-bootstrap replicates over the same f64 store against the serial oracle."""
+    st = synth.make_store(10_000_000, 200_000, 8.0, coverage=True, threads=min(32, os.cpu_count() or 8))
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps)
+    u, t = c_oracle.aux_counts(o)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps) as d:
+        assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0        # f64 products: the plain stream
+        cnt, info = d.em_run(None, 12, 0.0, 50)
+        assert info.niter == 12 and info.n_passes == 13
+        want, wi = c_oracle.em_par(o, max_iter=12, conv_thresh=0.0, min_iter_gate=50)
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, 1e-8, "c3 with coverage, 12 iterations")
+        assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads       # mass conservation
+        full, finfo = d.em_run(None, 1000, 1e-3, 50)                 # the reference's defaults (this store runs into max_iter)
+        assert finfo.n_passes == finfo.niter + (2 if finfo.converged else 1) and finfo.niter > 51
+        assert abs(full.sum() - st.n_reads) < 1e-7 * st.n_reads
+        assert np.all(full >= u - 1e-6) and np.all(full <= t + 1e-6)  # unique <= count <= total
+        W = np.stack([d.bootstrap_weights(5, 0), np.ones(st.n_reads, dtype=np.uint32)])
+        bout, binfo = d.bootstrap(2, row_w_all=W, max_iter=6, conv_thresh=0.0)
+        wantb, _ = c_oracle.do_em(o, row_w=W[0], max_iter=6, conv_thresh=0.0)
+        assert binfo[0].niter == 6 and binfo[0].n_passes == 7
+        assert_counts_close(bout[0], wantb, st.n_reads, st.n_txps, 1e-8, "c3 with coverage, batched bootstrap replicate")
+        assert abs(bout[1].sum() - st.n_reads) < 1e-7 * st.n_reads
+
+
+@pytest.mark.timeout(900)
+def test_c5_slice_of_one_gpu_properties():
+    """BASELINE configs[4] at the size ONE GPU sees when 5 k cells are dealt to 8: 625 cells x 50 k reads (31 M reads,
+    250 M alignments, one batched store: wide windows, fused fold, live-tile compaction).  No oracle at this size: per
+    cell mass conservation and unique <= count <= total (aux counts over the cell's own rows), cells stop at their own
+    iterations, and a slice of the batch equals the same cells run as a batch of their own."""
+    n_cells, per_cell, T = 625, 50_000, 60_000
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, per_cell, T, seed=37, threads=min(32, os.cpu_count() or 4))
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=1000, convergence_thresh=1e-3)
+    assert out.shape == (n_cells, T)
+    assert np.abs(out.sum(axis=1) - per_cell).max() < 1e-6 * per_cell
+    passes = np.array([i.n_passes for i in infos])
+    assert passes.min() >= 53 and passes.max() <= 1001 and len(set(passes.tolist())) > 20
+    for c in (0, 311, 624):   # unique <= count <= total, from the cell's own alignments
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        lens = (row_ptr[r0 + 1:r1 + 1] - row_ptr[r0:r1]).astype(np.int64)
+        tot = np.bincount(tid[a0:a1], minlength=T)
+        uniq = np.bincount(tid[a0:a1][np.repeat(lens == 1, lens)], minlength=T)
+        assert np.all(out[c] >= uniq - 1e-6) and np.all(out[c] <= tot + 1e-6), c
+    # the first 8 cells as a batch of their own: the same answers (a cell's run does not depend on its batch)
+    r8 = int(cell_off[8]); a8 = int(row_ptr[r8])
+    out8, infos8 = oarfish_amd.em_cells(cell_off[:9], row_ptr[:r8 + 1], tid[:a8], p[:a8], None, T, max_iter=1000,
+                                        convergence_thresh=1e-3)
+    for c in range(8):
+        assert infos8[c].niter == infos[c].niter
+        assert_counts_close(out8[c], out[c], per_cell, T, 1e-9, f"cell {c}: batch of 8 vs batch of 625")
 
 
 @pytest.mark.parametrize("name", ["c2"])
