@@ -125,8 +125,8 @@ struct DeviceTiled {
     // dictionary-coded local weights (oem_layout_dict.hip), when the store has at most 256 distinct ones
     uint32_t dict_n = 0;           // entries of the table (0: not coded, the kernels read w32)
     bool dict_fused = false;       // <= 128 entries: the index sits in the spare bits of the window codes, no widx
-    bool dict_words = false;       // 257 .. 768 entries: 16-bit indices, two per word, in the geometry of the codes
-    float *dict = nullptr;         // 768 floats, ascending, [0] = 0.0
+    bool dict_words = false;       // 257 .. 1024 entries: 16-bit indices, two per word, in the geometry of the codes
+    float *dict = nullptr;         // 1024 floats, ascending, [0] = 0.0
     uint32_t *widx = nullptr;      // four one-byte indices per word, SELL layout of the tiles (dict_words: see above)
     uint32_t *i_base = nullptr;    // n_tiles + 1: first index row of each tile
     uint8_t *r_wi = nullptr;       // n_remote: table index of each remote record's weight

@@ -11,9 +11,9 @@
 // over -- lossless, no tolerance involved.  Measured at C3 (98 distinct weights): the pass
 // 0.199 -> 0.176 ms (profiles/r03_notes.md): the pass follows its bytes.
 //
-// Round 4: 257 .. 768 distinct weights (what long reads produce: integer score gaps up to 5 % of a best score in the
+// Round 4: 257 .. 1024 distinct weights (what long reads produce: integer score gaps up to 5 % of a best score in the
 // thousands, and exp(-gap / 5) reaches 0 in f32 at a gap of ~520) take 16-bit indices, two per u32 in the geometry
-// of the window codes (2 + 2 bytes per local alignment), from a 3 KiB table in LDS.
+// of the window codes (2 + 2 bytes per local alignment), from a 4 KiB table in LDS.
 //
 // Stores with more distinct weights, f64 weights (the coverage model multiplies a second factor in) or the wide
 // window cap (per-cell batches: see build_weight_dictionary) keep the f32 stream; `oem_store_opts.weight_coding = 1` keeps it for any store.
@@ -35,8 +35,8 @@ namespace oem {
 namespace {
 
 constexpr int kDT = 256;
-constexpr uint32_t kDictMax = 768;   // entries of the largest table (16-bit indices; 3 KiB of LDS in k_em_tile: five
-                                     // 31 KiB workgroups per CU -- with 4 KiB, 5 x 32 KiB = the whole LDS, only four were resident)
+constexpr uint32_t kDictMax = 1024;  // entries of the largest table (16-bit indices; 4 KiB of LDS in k_em_tile, whose 16-bit
+                                     // instantiation runs four workgroups per CU: all its slices register-resident)
 constexpr uint32_t kSetSlots = 4096; // open addressing, <= kDictMax + 1 live keys
 constexpr uint32_t kEmptyKey = 0xffffffffu; // a NaN pattern: never a weight of the store (NaN rows were dropped at upload)
 
@@ -302,7 +302,7 @@ int build_weight_dictionary(oem_store *s)
         OEM_HIP(hipMalloc((void **)&t.dict, sizeof(float) * kDictMax));
         OEM_HIP(hipMemcpyAsync(t.dict, dict.data(), sizeof(float) * kDictMax, hipMemcpyHostToDevice, st));
         if (keys.size() > 256) {
-            // 257 .. 768 distinct weights (long reads: integer score gaps up to 5 % of a best score in the thousands):
+            // 257 .. 1024 distinct weights (long reads: integer score gaps up to 5 % of a best score in the thousands):
             // 16-bit indices beside the codes; the remote records keep their f32 weights
             uint32_t c_rows = last.c_base;
             for (uint32_t i = 0; i < kTileSlices; ++i) c_rows += (last.width[i] + 1u) >> 1;

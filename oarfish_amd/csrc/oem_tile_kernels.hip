@@ -91,9 +91,49 @@ struct SliceRegs {
 // stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
 // (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
 // no weight stream at all, a local alignment is its two code bytes; 3 WORDS: 16-bit indices, two per u32, stored in
-// the geometry of the window codes (257..768 distinct weights -- long reads with score gaps in the hundreds).
+// the geometry of the window codes (257..1024 distinct weights -- long reads with score gaps in the hundreds).
 constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2, kWWords = 3;
-template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 768 : kDict != kWPlain ? 256 : 1; }
+template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 1024 : kDict != kWPlain ? 256 : 1; }
+
+// Register sets and launch bound (waves per SIMD the compiler must leave room for) of k_em_tile by weight coding:
+// how many of a wavefront's slices sit in registers before the fold starts (see kSets in the kernel).  Measured
+// (profiles/r04_notes.md; C3 pass, two sets at five workgroups per CU before): fused / byte codes, 4 / 6 registers a
+// set: all five sets, still five workgroups per CU: 0.168 -> 0.150 ms; the f32 stream, 12 registers a set: five sets at
+// FOUR workgroups per CU: 0.196 -> 0.177 (four sets 0.181, three 0.186); 16-bit indices, 8 a set: five sets at four
+// workgroups 0.176 -> 0.166 (three sets at five: 0.170); f64 weights (coverage), 20 a set and four workgroups per CU
+// either way: three sets 0.248 -> 0.239; the wide-window kernel of the per-cell batches: no difference (two).
+// The defaults can be overridden per build for A/B (scripts/build_variant.sh).
+#ifndef OEM_SETS_FUSED
+#define OEM_SETS_FUSED 5
+#endif
+#ifndef OEM_SETS_BYTES
+#define OEM_SETS_BYTES 5
+#endif
+#ifndef OEM_SETS_WORDS
+#define OEM_SETS_WORDS 5
+#endif
+#ifndef OEM_SETS_F32
+#define OEM_SETS_F32 5
+#endif
+#ifndef OEM_SETS_F64
+#define OEM_SETS_F64 3
+#endif
+#ifndef OEM_SETS_WIDE
+#define OEM_SETS_WIDE 2
+#endif
+#ifndef OEM_WAVES_WORDS
+#define OEM_WAVES_WORDS 4
+#endif
+template <typename WT, int kDict> constexpr int tile_sets()
+{
+    return sizeof(WT) == 8 ? OEM_SETS_F64 : kDict == kWFused ? OEM_SETS_FUSED : kDict == kWBytes ? OEM_SETS_BYTES
+                                          : kDict == kWWords ? OEM_SETS_WORDS : OEM_SETS_F32;
+}
+template <typename WT, int kDict> constexpr int tile_min_waves()
+{
+    return sizeof(WT) == 8 ? 2 : (kDict == kWFused || kDict == kWBytes) ? 5 : kDict == kWWords ? OEM_WAVES_WORDS
+                                                                           : (OEM_SETS_F32 > 2 ? 4 : 2);
+}
 __device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
 template <int kDict>
 __device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
@@ -359,7 +399,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     }
 }
 
-template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, int kDict>
+template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, int kDict, int kSetsT>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
@@ -443,9 +483,19 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 
     OEM_PROBE(1); // descriptor in hand, slice addresses derived
     // ---- every long-latency load of the tile is issued here, before any use ---------
-    // The first slice of the wavefront is loaded here; the rest are prefetched one slice ahead of
-    // the fold (two register sets, ping-pong).
-    constexpr uint32_t kSets = 2;
+    // Register sets of the wavefront's slices.  Slice 0 -- the widest -- takes sets 0 and 1 (its alignments 0..7 and
+    // 8..15, fold_first); slices 1 .. kTop are loaded HERE into sets 2 .., the others later, into the sets the fold
+    // has finished with: the first of them into set 0 half way through slice 0's fold, the next into set 1 after it,
+    // the third (two sets only) into set 0 after slice 1's fold.  With two sets that is one slice of look-ahead, and
+    // every fold then waited a whole loaded round trip for operands requested one fold -- a microsecond of LDS work
+    // -- earlier: the slices took ~2 us each whatever they did (profiles/r04_notes.md).  A coded slice is a handful
+    // of registers (fused: its four code words), so those kernels keep all of them resident (kSets = 5).
+    constexpr uint32_t kSets = kSetsT;
+    static_assert(kSets >= 2 && kSets <= kPerWave + 1, "two sets for slice 0, at most one more per further slice");
+    constexpr uint32_t kTop = kSets - 2 < kPerWave - 1 ? kSets - 2 : kPerWave - 1; // slices 1 .. kTop are loaded at the top
+    // set a slice is folded from; late slice L (0-based) = slice kTop + 1 + L goes into set L % kSets
+    auto set_of = [](uint32_t q) constexpr -> uint32_t { return q <= kTop ? q + 1 : (q - kTop - 1) % kSets; };
+    constexpr uint32_t kLate0 = kTop + 1 < kPerWave ? kTop + 1 : 0; // the slice loaded at fold_first's hand-over (0: none)
     // the theta window depends on the descriptor alone: its loads go out first, so that (loads return in
     // order) waiting for them waits for nothing else
     constexpr uint32_t kPer = (kWinT + kTileThreads - 1) / kTileThreads;
@@ -466,6 +516,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
                                     wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u,
                                     kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : kDict == kWWords ? iptr(0) + (kCh / 2) * 64 : nullptr);
+#pragma unroll
+    for (uint32_t q = 1; q <= kTop; ++q)
+        load_slice<WT, kCh, kNT, kDict>(R[q + 1], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q], iptr(q));
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
     uint32_t rrow[kRem];  // their read (index inside the tile)
@@ -546,24 +599,26 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(5);
 
     // ---- local alignments: one read per lane, all operands already in registers -----
-    // slice 0: 16 register-resident alignments in both sets; it releases R[0] to slice 1's prefetch half way
+    // slice 0: 16 register-resident alignments in sets 0 and 1; it releases set 0 to the first late slice half way
     if (wave < td.n_slices)
         fold_first<WT, kCh, kCopies, kNT, kDict>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
-                                                 td, theta_l, cnt_l, den_l, row_w_perm, kPerWave > 1,
-                                                 w + (size_t)woff[kPerWave > 1 ? 1 : 0] * 64, codes + (size_t)coff[kPerWave > 1 ? 1 : 0] * 64,
-                                                 wid[kPerWave > 1 ? 1 : 0], iptr(0), iptr(kPerWave > 1 ? 1 : 0), dict_l, exp_mask);
-    else if (kPerWave > 1)
-        load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1], iptr(1));
+                                                 td, theta_l, cnt_l, den_l, row_w_perm, kLate0 != 0,
+                                                 w + (size_t)woff[kLate0] * 64, codes + (size_t)coff[kLate0] * 64,
+                                                 wid[kLate0], iptr(0), iptr(kLate0), dict_l, exp_mask);
+    else if (kLate0 != 0)
+        load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[kLate0] * 64, codes + (size_t)coff[kLate0] * 64, lane, wid[kLate0], iptr(kLate0));
     OEM_PROBE(6);
-    // slices 1..: slice q sits in R[(q - 1) % 2], slice q + 1 is prefetched into the other set
+    // slices 1..: before slice q is folded, the late slice whose set the previous fold has just released is requested
 #pragma unroll
     for (uint32_t q = 1; q < kPerWave; ++q) {
         const uint32_t s = slice_of(q);
-        if (q + 1 < kPerWave)
-            load_slice<WT, kCh, kNT, kDict>(R[q % kSets], w + (size_t)woff[q + 1] * 64, codes + (size_t)coff[q + 1] * 64, lane,
-                       wid[q + 1], iptr(q + 1 < kPerWave ? q + 1 : q));
+        constexpr uint32_t kNone = 0xffffffffu;
+        const uint32_t late = kTop + 1 + q < kPerWave ? kTop + 1 + q : kNone; // late slice L = q: after fold q - 1, into set q % kSets
+        if (late != kNone)
+            load_slice<WT, kCh, kNT, kDict>(R[q % kSets], w + (size_t)woff[late != kNone ? late : 0] * 64,
+                       codes + (size_t)coff[late != kNone ? late : 0] * 64, lane, wid[late != kNone ? late : 0], iptr(late != kNone ? late : 0));
         if (s < td.n_slices)
-            fold_slice<WT, kCh, kCopies, kDict>(R[(q - 1) % kSets], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
+            fold_slice<WT, kCh, kCopies, kDict>(R[set_of(q)], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
                        theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l, exp_mask);
         OEM_PROBE(6 + q); // wave 0's slice q folded (its operands had to land first)
     }
@@ -672,11 +727,11 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     if (n_tiles == 0) return;
     const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 4, kNT, kWin, kPacked, kDict>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), 4, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
 }

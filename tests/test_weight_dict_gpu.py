@@ -1,6 +1,6 @@
 """GPU tests of the dictionary-coded local weights (oem_layout_dict.hip): as_prob = exp((score - best) / D) with
 integer scores (oarfish_types.rs:1100-1114) takes few distinct values; up to 128 of them are coded into the spare
-bits of the window codes, up to 256 as one-byte indices, up to 768 as 16-bit indices into a table of the f32
+bits of the window codes, up to 256 as one-byte indices, up to 1024 as 16-bit indices into a table of the f32
 values -- lossless -- and anything else keeps the f32 stream."""
 import numpy as np
 import pytest
@@ -32,7 +32,7 @@ def test_coded_and_plain_weights_give_the_same_answer_and_the_oracles():
     for coding in (0, 1):
         with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T, weight_coding=coding) as d:
             n = d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
-            assert (n > 0) == (coding == 0) and n <= 768
+            assert (n > 0) == (coding == 0) and n <= 1024
             assert d.info(_lib.OEM_INFO_TILES) > 0 and 0 < d.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS) < st.nnz
             m = d.m_step(theta)
             cnt, info = d.em_run(None, 300, 1e-3, 50)
@@ -48,10 +48,10 @@ def test_coded_and_plain_weights_give_the_same_answer_and_the_oracles():
 
 
 @pytest.mark.parametrize("n_distinct,coded", [(3, True), (127, True), (128, True), (255, True), (256, True), (600, True),
-                                              (767, True), (768, False), (5000, False)])
-def test_the_table_holds_at_most_768_values_including_the_zero_of_the_padding(n_distinct, coded):
+                                              (1023, True), (1024, False), (5000, False)])
+def test_the_table_holds_at_most_1024_values_including_the_zero_of_the_padding(n_distinct, coded):
     """127 | 128 distinct values + the padding's 0.0: fused index | byte indices; 255 | 256: bytes | 16-bit indices;
-    767 | 768: 16-bit indices | the f32 stream."""
+    1023 | 1024: 16-bit indices | the f32 stream."""
     st = synth.make_store(40_000, 3_000, seed=7)
     rng = np.random.default_rng(n_distinct)
     p = _weights_with(n_distinct, st.nnz, rng)
@@ -73,7 +73,7 @@ def test_continuous_and_coverage_weights_keep_their_streams():
         o = c_oracle.Store(st.row_ptr, st.tid, p if cov is None else st.as_prob, cov, st.n_txps)
         want, _ = c_oracle.do_em(o, max_iter=30, conv_thresh=0.0)
         with DeviceStore(st.row_ptr, st.tid, p if cov is None else st.as_prob, cov, st.n_txps) as d:
-            assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0   # > 768 distinct f32 values / f64 products
+            assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0   # > 1024 distinct f32 values / f64 products
             got, _ = d.em_run(None, 30, 0.0, 50)
         assert_counts_close(got, want, st.n_reads, st.n_txps, 1e-9, "plain stream")
 
@@ -133,7 +133,7 @@ def test_uniform_score_gaps_take_the_16_bit_indices():
     st = synth.make_store(150_000, 9_000, seed=43, gaps="uniform")
     T = st.n_txps
     n_vals = len(np.unique(st.as_prob))
-    assert 256 < n_vals <= 767, n_vals
+    assert 256 < n_vals <= 1023, n_vals
     o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
     theta = np.random.default_rng(3).lognormal(0, 1.5, T)
     want_m = c_oracle.m_step(o, theta)
