@@ -690,17 +690,28 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     const bool is_final = (final_ >> b) & 1u, is_live = ((running | final_) >> b) & 1u;
     double rel = 0.0;
     const size_t n_elem = (size_t)p.n_txps * kB;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_elem; j += (size_t)gridDim.x * blockDim.x) {
-        if (!is_live) continue;
-        const size_t i = j / kB, ib = (size_t)b * p.n_txps + i;
-        const double cc = cnt[j];
-        cnt[j] = 0.0;
-        if (is_final) {
-            out[ib] = cc;                               // em.rs:254
-        } else {
-            const double pc = theta[j];
-            if (pc > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc - pc) / pc); // em.rs:195-199
-            theta[j] = cc;                              // em.rs:204 (zeroing of small values: k_em_tile_e reads them as 0)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (is_live) { // (the loads of four elements go out before the first is looked at: the sweep is latency, not bytes)
+        for (size_t j0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j0 < n_elem; j0 += 4 * stride) {
+            double cc[4], pc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t j = j0 + k * stride, jc = j < n_elem ? j : j0;
+                cc[k] = cnt[jc];
+                pc[k] = is_final ? 0.0 : theta[jc];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t j = j0 + k * stride;
+                if (j >= n_elem) break;
+                cnt[j] = 0.0;
+                if (is_final) {
+                    out[(size_t)b * p.n_txps + j / kB] = cc[k];                           // em.rs:254
+                } else {
+                    if (pc[k] > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc[k] - pc[k]) / pc[k]); // em.rs:195-199
+                    theta[j] = cc[k];                           // em.rs:204 (zeroing of small values: k_em_tile_e reads them as 0)
+                }
+            }
         }
     }
     __shared__ double smax[kRelB / 64][kB];
