@@ -2,9 +2,13 @@
 // ONE store over a concatenated transcript space and share every pass (oem_multi_kernels.hip); groups the tiler
 // declines run cell after cell over the caller-order CSR.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "oem_driver.h"
@@ -16,6 +20,14 @@ namespace {
 // group's stream around the loop), for oem_cells_last_timing.
 thread_local double t_cells_loop_ms = 0.0;
 thread_local uint64_t t_cells_batched_passes = 0;
+// (the groups of one call may run on two host threads: they add into the call's accumulators under this lock,
+// and the calling thread copies them into its thread-local pair at the end)
+struct CellsTiming {
+    std::mutex mu;
+    double loop_ms = 0.0;
+    uint64_t passes = 0;
+};
+thread_local CellsTiming *t_timing = nullptr;
 
 // All cells in one store over the concatenated transcript space; every pass serves every
 // unfinished cell.  Returns *used = false (nothing done) when the batch form does not apply.
@@ -132,8 +144,11 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             if (rc2 == OEM_OK && hipEventRecord(ev1, s->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
-                    t_cells_loop_ms += ms;
-                    t_cells_batched_passes += launched;
+                    if (t_timing) {
+                        std::lock_guard<std::mutex> lk(t_timing->mu);
+                        t_timing->loop_ms += ms;
+                        t_timing->passes += launched;
+                    }
                 }
             }
             hipEventDestroy(ev0);
@@ -277,6 +292,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
     // that bound the batched store (transcript space < 2^32, <= 2^30 alignments, and the layout
     // builder's tile x bucket table); each group is one batched run on the device.
     const uint64_t max_group_nnz = (uint64_t)knob("OEM_CELLS_GROUP_NNZ", 1l << 30); // testing build: small groups
+    std::vector<std::pair<uint32_t, uint32_t>> groups;
     uint32_t c0 = 0;
     while (c0 < n_cells) {
         uint32_t c1 = c0 + 1;
@@ -294,10 +310,63 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
                 break;
             ++c1;
         }
-        OEM_TRY(run_cells_group(cell_row_off, c0, c1, row_ptr, tid, as_prob, cov_prob, n_txps, device, max_iter,
-                                conv_thresh, out, infos));
+        groups.emplace_back(c0, c1);
         c0 = c1;
     }
+    // Groups are independent runs.  With several of them two host threads draw groups from one counter, each group
+    // on its own stream: one group's upload, layout build and read-back run under the other's EM loop, and the tail
+    // of a loop -- the few cells that run into max_iter, a handful of live tiles per pass -- shares the device with
+    // the other group's full passes instead of leaving it idle (single_cell.rs:96-150 runs its cells on N worker
+    // threads for the same reason).
+    CellsTiming timing;
+    std::atomic<size_t> next{0};
+    constexpr int kMaxWorkers = 4;
+    int n_workers = (int)knob("OEM_CELLS_WORKERS", 2);
+    if (n_workers > kMaxWorkers) n_workers = kMaxWorkers;
+    if ((size_t)n_workers > groups.size()) n_workers = (int)groups.size();
+    if (n_workers < 1) n_workers = 1;
+    int rcs[kMaxWorkers] = {OEM_OK, OEM_OK, OEM_OK, OEM_OK};
+    std::string errs[kMaxWorkers];
+    auto work = [&](int wk) {
+        t_timing = &timing;
+        if (wk != 0 && hipSetDevice(device) != hipSuccess) {
+            rcs[wk] = OEM_ERR_HIP;
+            errs[wk] = "hipSetDevice failed in a per-cell worker";
+            return;
+        }
+        try {
+            for (;;) {
+                const size_t g = next.fetch_add(1);
+                bool failed = false;
+                for (int k = 0; k < kMaxWorkers; ++k) failed = failed || rcs[k] != OEM_OK;
+                if (g >= groups.size() || failed) break;
+                rcs[wk] = run_cells_group(cell_row_off, groups[g].first, groups[g].second, row_ptr, tid, as_prob, cov_prob,
+                                          n_txps, device, max_iter, conv_thresh, out, infos);
+                if (rcs[wk] != OEM_OK) break;
+            }
+        } catch (const std::exception &e) {
+            rcs[wk] = fail(OEM_ERR_OOM, "per-cell worker: %s", e.what());
+        } catch (...) {
+            rcs[wk] = fail(OEM_ERR_STATE, "per-cell worker: unknown C++ exception");
+        }
+        if (rcs[wk] != OEM_OK && errs[wk].empty()) errs[wk] = last_error_text(); // (the message is thread-local)
+        t_timing = nullptr;
+    };
+    {
+        struct Joiner { // (a std::thread constructor that throws must not leave joinable threads behind)
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+        } pool;
+        try {
+            for (int wk = 1; wk < n_workers; ++wk) pool.th.emplace_back(work, wk);
+        } catch (...) { // fewer threads: the ones that started take all the groups
+        }
+        work(0);
+    }
+    t_cells_loop_ms = timing.loop_ms;
+    t_cells_batched_passes = timing.passes;
+    for (int wk = 0; wk < kMaxWorkers; ++wk)
+        if (rcs[wk] != OEM_OK) return fail(rcs[wk], "%s", errs[wk].c_str());
     return OEM_OK;
     OEM_API_END("oem_em_run_cells")
 }
