@@ -38,6 +38,8 @@
 // by itself: RUNNING -(stopping rule em.rs:212 / max_iter em.rs:181)-> FINAL (theta < 1e-5
 // read as 0, em.rs:238-242; one more pass, em.rs:245-252) -> FINISHED (counts parked in
 // `out`, slot ignored from then on, handed the next replicate by the host).
+#include <atomic>
+
 #include "oem_internal.h"
 
 namespace oem {
@@ -845,9 +847,14 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         constexpr size_t kFoldLds = sizeof(double) * kBucket * kFS;
         static_assert(kB % kFS == 0, "the fold takes the slots four at a time");
         static_assert(kFoldLds <= 160u * 1024u, "the fold window of all slots must fit the LDS of a CU");
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_remote_fold_b),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFoldLds);
-        OEM_HIP(attr);
+        // (a function attribute belongs to the device that is current: once per device of this process)
+        static std::atomic<unsigned long long> attr_set{0ull};
+        const unsigned long long bit = 1ull << (s->device & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            OEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_remote_fold_b),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFoldLds));
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
         hipLaunchKernelGGL(k_remote_fold_b, dim3(t.n_buckets * n_groups, kB / kFS), dim3(kFoldThreadsB), kFoldLds, bb.stream,
                            t.bucket_base, bb.queue, t.q_dst, bb.theta, bb.cnt, bb.state, n_groups, s->csr.n_txps);
         OEM_HIP(hipGetLastError());
