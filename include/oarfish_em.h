@@ -323,7 +323,7 @@ void oem_comm_destroy(oem_comm *comm);
  * em.rs:338-341); larger exchanges stay with RCCL when the communicator has one.
  *   oem_comm_create(NULL, rank, n_ranks > 1, ...) makes a communicator without RCCL;
  *   oem_comm_p2p_export: allocates this rank's exchange buffer for vectors of up to `capacity` doubles
- *     (n_txps, or 2 * n_txps * 4 to cover the batched bootstrap of a row-sharded store) and writes its
+ *     (n_txps, or n_txps * 4 to cover the batched bootstrap of a row-sharded store) and writes its
  *     handle (OEM_P2P_HANDLE_BYTES bytes), which the host gathers over whatever it has (as the unique id);
  *   oem_comm_p2p_connect: `all_handles` = the n_ranks handles in rank order; maps the peers' buffers.
  * All ranks must export the same capacity.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only

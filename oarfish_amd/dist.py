@@ -196,7 +196,7 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
     oem_p2p.hip -- also the only way to run several ranks on ONE device, which RCCL refuses), or
     "both" (RCCL for large vectors, peer to peer for the count vector; ``comm.p2p`` says whether the
     peer-to-peer side came up on every rank -- if it did not, RCCL serves everything).
-    ``p2p_capacity``: doubles per exchange buffer (n_txps, or 2 * n_txps * 4 to cover a row-sharded
+    ``p2p_capacity``: doubles per exchange buffer (n_txps, or n_txps * 4 to cover a row-sharded
     batched bootstrap).  ``p2p_self_check``: connecting ends with a checked exchange in both shapes against a
     closed-form sum (OEM_COMM_OPT_P2P_SELF_CHECK) -- a rank whose check fails takes the whole communicator to
     RCCL ("both") or raises ("p2p"); ``comm.p2p_error`` then carries the first failing rank's message on every
