@@ -511,16 +511,19 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     for (uint32_t u = 0; u < kDictPer; ++u) // 1 KiB (4 KiB: 16-bit indices), L2-resident
         dict_v[u] = (kDict != kWPlain && tx + u * kTileThreads < (uint32_t)dict_entries<kDict>()) ? dict[tx + u * kTileThreads] : 0.0f;
     SliceRegs<WT, kCh> R[kSets];
-    load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
-    // alignments 8..15 of the first slice, into the second set (see fold_first)
-    load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
-                                    wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u,
-                                    kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : kDict == kWWords ? iptr(0) + (kCh / 2) * 64 : nullptr);
+    auto load_slices = [&]() {
+        load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
+        // alignments 8..15 of the first slice, into the second set (see fold_first)
+        load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
+                                        wid[0] > (uint32_t)kCh ? wid[0] - kCh : 0u,
+                                        kDict == kWBytes ? iptr(0) + (kCh / 4) * 64 : kDict == kWWords ? iptr(0) + (kCh / 2) * 64 : nullptr);
 #pragma unroll
-    for (uint32_t q = 1; q <= kTop; ++q)
-        load_slice<WT, kCh, kNT, kDict>(R[q + 1], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q], iptr(q));
+        for (uint32_t q = 1; q <= kTop; ++q)
+            load_slice<WT, kCh, kNT, kDict>(R[q + 1], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q], iptr(q));
+    };
 
     double rx[kRem];      // theta[t] * w of this thread's remote alignments
+
     uint32_t rrow[kRem];  // their read (index inside the tile)
     uint32_t rslot[kRem]; // their slot in the bucket-major queue
     constexpr bool kRemIdx = kDict == kWBytes || kDict == kWFused; // byte-coded stores: a remote record's weight is a table index byte too
@@ -542,10 +545,15 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
                 if (kRemIdx) ri[k] = ld_stream<kNT>(&r_wi[o]);
                 else rw[k] = ld_stream<kNT>(&r_w[o]);
             }
+            // (the records are requested ahead of the slices: loads return in order, so the gathers that hang on
+            // the records go out one round trip after the kernel starts, not behind all the slices' data -- 1 % of
+            // the pass now that every slice is requested up here)
+            load_slices();
 #pragma unroll
             for (int k = 0; k < kRem; ++k)
                 if (tx + k * kTileThreads >= td.remote_cnt) { rw[k] = (WT)0; ri[k] = 0u; }
         } else {
+            load_slices();
 #pragma unroll
             for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; ri[k] = 0u; rrow[k] = 0; }
         }
