@@ -51,3 +51,25 @@ def test_synth_is_deterministic_and_well_formed():
     cv = synth.make_store(5_000, 500, seed=5, coverage=True)
     s = np.add.reduceat(cv.cov_prob, cv.row_ptr[:-1].astype(np.int64))
     np.testing.assert_allclose(s, 1.0, rtol=1e-12)
+
+
+def test_long_read_score_gaps_of_the_generator():
+    """synth.make_store(gaps="uniform"): deficits uniform on [0, 0.05 best] for best scores up to 20 000 -- what
+    oarfish_types.rs:1107-1118 admits -- give a few hundred distinct f32 weights (exp(-gap / 5) reaches 0 near a gap
+    of 520), more than the byte-coded weight table takes and within the 16-bit one; the default generator stays
+    under 128.  Seeded: the same store twice."""
+    import numpy as np
+    from oarfish_amd import synth
+    a = synth.make_store(60_000, 4_000, seed=5, gaps="uniform")
+    b = synth.make_store(60_000, 4_000, seed=5, gaps="uniform")
+    assert np.array_equal(a.tid, b.tid) and np.array_equal(a.as_prob, b.as_prob) and np.array_equal(a.row_ptr, b.row_ptr)
+    n = len(np.unique(a.as_prob))
+    assert 256 < n <= 1023, n
+    assert a.as_prob.max() == 1.0 and a.as_prob.min() >= 0.0
+    first = a.row_ptr[:-1].astype(np.int64)
+    assert np.all(np.maximum.reduceat(a.as_prob, first) == 1.0)      # every read keeps its best alignment at weight 1
+    g = synth.make_store(60_000, 4_000, seed=5)
+    assert len(np.unique(g.as_prob)) <= 128
+    import pytest
+    with pytest.raises(ValueError):
+        synth.make_store(100, 10, gaps="bimodal")
