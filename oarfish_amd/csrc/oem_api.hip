@@ -334,6 +334,7 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
         const bool sparse = n_reads < 2 * (uint64_t)(n_txps ? n_txps : 1);
         win_cap = (sparse && n_reads >= 1000000) ? kWinWide : kWin;
     }
+    if (win_cap == kWinWide) win_cap = kWinWideLds; // (the wide cap as the kernels hold it: oem_layout.h)
     // host copy of the relabelled transcript ids, only for the host builder
     std::vector<uint32_t> vt;
     auto host_tids = [&]() -> const uint32_t * {

@@ -253,9 +253,11 @@ int build_weight_dictionary(oem_store *s)
 {
     DeviceTiled &t = s->tiled;
     if (!t.present || t.n_tiles == 0 || s->csr.w_is_f64 || !t.w32) return OEM_OK;
-    // The wide-window instantiation of k_em_tile holds exactly four 40 KiB workgroups per CU: one more KiB for the
-    // table makes that three, and the per-cell loop it serves 5 % slower (measured: 647 -> 680 ms for 625 cells).
-    if (t.win_cap > kWin) return OEM_OK;
+    // The wide-window instantiation of k_em_tile holds exactly four 40 KiB workgroups per CU with the 1 KiB table of
+    // the BYTE coding (its tiles are cut for 1984 transcripts, oem_layout.h: round 3 had 2048 and the table made it
+    // three workgroups, 5 % slower).  Its codes have no spare bits for a fused index and the CU no room for the
+    // 4 KiB table of 16-bit indices: a wide store is byte-coded (<= 256 distinct weights) or keeps the f32 stream.
+    const bool wide = t.win_cap > kWin;
     hipStream_t st = s->stream;
     uint32_t *gtab = nullptr, *small = nullptr, *sizes = nullptr, *begins = nullptr;
     void *tmp = nullptr;
@@ -272,7 +274,7 @@ int build_weight_dictionary(oem_store *s)
         OEM_HIP(hipMalloc((void **)&small, sizeof(uint32_t) * 4));
         OEM_HIP(hipMemsetAsync(gtab, 0xff, sizeof(uint32_t) * kSetSlots, st));
         OEM_HIP(hipMemsetAsync(small, 0, sizeof(uint32_t) * 4, st));
-        const uint32_t limit = kDictMax; // (0.0 is one of them: the SELL padding; a store without padding gets it added below)
+        const uint32_t limit = wide ? 256u : kDictMax; // (0.0 is one of them: the SELL padding; a store without padding gets it added below)
         uint64_t g = (n + kDT - 1) / kDT;
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(k_dict_collect, dim3((uint32_t)g), dim3(kDT), 0, st, t.w32, n, limit, gtab, small, small + 1);
@@ -295,7 +297,7 @@ int build_weight_dictionary(oem_store *s)
         if (std::find(keys.begin(), keys.end(), 0u) == keys.end()) keys.push_back(0u); // index 0 = weight 0.0
         for (uint32_t k : keys)
             if (k & 0x80000000u) return OEM_OK; // a negative (or -0.0) weight: not ordered like its bits; keep f32
-        if (keys.size() > kDictMax) return OEM_OK;
+        if (keys.size() > (wide ? 256u : kDictMax)) return OEM_OK;
         std::sort(keys.begin(), keys.end());
         std::vector<float> dict(kDictMax, 0.0f);
         for (size_t i = 0; i < keys.size(); ++i) std::memcpy(&dict[i], &keys[i], sizeof(float));
@@ -336,7 +338,7 @@ int build_weight_dictionary(oem_store *s)
                 OEM_HIP(hipGetLastError());
             }
         }
-        if (keys.size() <= 128 && knob("OEM_DICT_NO_FUSE", 0) == 0) { // (knob: testing build, reaches the byte-stream coding)
+        if (keys.size() <= 128 && !wide && knob("OEM_DICT_NO_FUSE", 0) == 0) { // (knob: testing build, reaches the byte-stream coding)
             // the index fits the spare bits of the window codes: no stream of its own
             // (checked first, written second: a store that does not fit keeps its codes as they are and takes the
             // byte stream below)

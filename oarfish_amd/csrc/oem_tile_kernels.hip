@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const uint8_t *__restrict__ r_wi, const uint32_t *__restrict__ live_tiles)
 {
     __shared__ float dict_l[dict_entries<kDict>()]; // the distinct weights of a coded store (oem_layout_dict.hip)
-    __shared__ double theta_l[kWinT]; // kWin, or kWinWide with one count-window copy (sparse stores)
+    __shared__ double theta_l[kWinT]; // kWin, or kWinWideLds with one count-window copy (sparse stores)
     __shared__ double cnt_l[kWinT * kCopies];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
@@ -735,7 +735,7 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     if (n_tiles == 0) return;
     const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWide, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
     else
