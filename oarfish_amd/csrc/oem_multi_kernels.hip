@@ -86,21 +86,46 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
     for (uint32_t i = threadIdx.x; i < kBucket; i += kFT) acc[i] = 0.0;
     __syncthreads();
     const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
-    for (uint32_t o = q0 + threadIdx.x; o < q1; o += kFT) {
-        const double v = queue[o];
-        if (v != 0.0) __hip_atomic_fetch_add(&acc[q_dst[o]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // four loads in flight per thread (a cell's bucket has a few entries per thread: one round trip instead of one
+    // per entry); entries past the range are clamped to its last one and skipped at the point of use
+    for (uint32_t o = q0 + threadIdx.x; o < q1; o += 4 * kFT) {
+        double v[4];
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t oo = o + k * kFT, oc = oo < q1 ? oo : q1 - 1;
+            v[k] = queue[oc];
+            d[k] = q_dst[oc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (o + k * kFT < q1 && v[k] != 0.0)
+                __hip_atomic_fetch_add(&acc[d[k]], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kBucket && t0 + i < n_txps; i += kFT) {
+    // the counts and abundances of this thread's window entries: requested together, then swept
+    constexpr uint32_t kPerThread = kBucket / kFT;
+    static_assert(kBucket % kFT == 0, "a thread sweeps kBucket / kFT window entries");
+    double cv[kPerThread], pv[kPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        const uint32_t i = threadIdx.x + k * kFT, t = t0 + i < n_txps ? t0 + i : n_txps - 1;
+        cv[k] = cnt[t];
+        pv[k] = theta[t];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        const uint32_t i = threadIdx.x + k * kFT;
+        if (t0 + i >= n_txps) break;
         const uint32_t t = t0 + i, p = t / T;
         const uint32_t phase = small ? phase_l[p - p0] : st[p].phase;
         if (phase == kPhaseFinished) continue;
-        const double cc = cnt[t] + acc[i];
+        const double cc = cv[k] + acc[i];
         cnt[t] = 0.0;                                             // em.rs:207
         if (phase == kPhaseFinal) {
             out[t] = cc;                                          // em.rs:254
         } else {
-            const double pc = theta[t];
+            const double pc = pv[k];
             theta[t] = cc;                                        // em.rs:204
             if (pc > OEM_MIN_READ_THRESH) {                       // em.rs:195-199 (signed, floored at 0 by the max)
                 const double rel = (cc - pc) / pc;
