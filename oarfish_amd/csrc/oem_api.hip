@@ -335,6 +335,9 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
         win_cap = (sparse && n_reads >= 1000000) ? kWinWide : kWin;
     }
     if (win_cap == kWinWide) win_cap = kWinWideLds; // (the wide cap as the kernels hold it: oem_layout.h)
+    // reads per tile: small stores are cut finer (oem_layout.h); per-cell batches are large by construction
+    uint32_t tile_rows = (uint32_t)knob("OEM_TILE_ROWS", relabel || (opts && opts->problem_size) ? kTileRows : tile_rows_for(n_reads));
+    tile_rows = tile_rows < 64u ? 64u : tile_rows > kTileRows ? kTileRows : (tile_rows & ~63u);
     // host copy of the relabelled transcript ids, only for the host builder
     std::vector<uint32_t> vt;
     auto host_tids = [&]() -> const uint32_t * {
@@ -372,13 +375,13 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
         OEM_TRY(relabel_on_device());
         tm.lap("caller-order CSR upload");
         bool built = false;
-        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, win_cap, &built));
+        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, win_cap, tile_rows, &built));
         tm.lap("tiled layout build (device)");
         if (built) return OEM_OK;
         TiledHost h;
         const char *err = nullptr;
         if (build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                               opts ? opts->problem_size : 0u, win_cap)) {
+                               opts ? opts->problem_size : 0u, win_cap, tile_rows)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
             return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
@@ -400,7 +403,7 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
     TiledHost h;
     const char *err = nullptr;
     const bool tiled = build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                                          opts ? opts->problem_size : 0u, win_cap);
+                                          opts ? opts->problem_size : 0u, win_cap, tile_rows);
     tm.lap("tiled layout build (host)");
     up.join();
     tm.lap("wait for the CSR upload");

@@ -239,7 +239,7 @@ int launch_zero_small(oem_store *s, double *prev, double *curr, uint32_t n_txps)
 // Tiled E/M pass over the whole store (oem_layout.h): tile kernel + remote-bucket kernel.
 // row_w is in the caller's read order; it is permuted into tile order first.
 // oem_layout_device.hip: the tiled layout built on the device from the resident CSR
-int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built);
+int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, uint32_t tile_rows, bool *built);
 int build_weight_dictionary(oem_store *s); // oem_layout_dict.hip
 // oem_layout_pack.hip: slot table + packed remote records, after either builder
 int pack_remote_records(oem_store *s, uint32_t problem_size, bool keep_unpacked);

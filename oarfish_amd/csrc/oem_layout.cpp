@@ -64,7 +64,8 @@ struct RemoteRec {
 
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err, uint32_t problem_size, uint32_t win_cap)
+                        TiledHost *out, const char **err, uint32_t problem_size, uint32_t win_cap,
+                        uint32_t tile_rows)
 {
     (void)nnz;
     if (n_reads >= (1ull << 32)) {
@@ -148,7 +149,7 @@ bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const floa
                 if (kmax > pend) kmax = pend;
             }
             uint32_t end = pos + 1;
-            while (end < n_rows && end - pos < kTileRows && key[order[end]] <= kmax) ++end;
+            while (end < n_rows && end - pos < tile_rows && key[order[end]] <= kmax) ++end;
             tile_start.push_back(pos);
             tile_lo.push_back(lo);
             // A stray alignment that merely happens to fall inside [lo, lo + kWin) is cheaper as a

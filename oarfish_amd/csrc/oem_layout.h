@@ -51,6 +51,16 @@ static_assert((kTileRows - 1) >> (32 - kPackRowShift) == 0, "the read index must
 
 constexpr uint32_t kTileSlices = kTileRows / 64;
 
+// Reads per tile by store size.  A pass over a small store is ONE round of workgroups and lasts as long as a tile
+// lives; a wavefront walks its slices one after another, so a 125 k-read store (the row shard of one of eight ranks
+// at 1 M reads) is 160 workgroups of four slices per wavefront on a chip with 1280 resident slots.  Cut into
+// 256-read tiles the same store is 489 workgroups of one slice per wavefront: iteration 22.3 -> 20.0 us (250 k reads:
+// 23.6 -> 22.5).  A tile costs ~7 us whatever it holds (descriptor, window load / clear / flush, three barriers,
+// the remote round trips), so from 500 k reads on -- where the full tiles already cover the chip -- finer tiles
+// only LOSE: 1 M reads 36.3 -> 39.5 -> 46.3 us at 512 / 256 reads per tile, 10 M reads 168 -> 213 -> 321 us
+// (scripts/tile_rows_exp.py, profiles/r04_notes.md).
+inline uint32_t tile_rows_for(uint64_t n_reads) { return n_reads <= (1ull << 18) ? 256u : kTileRows; }
+
 // Everything a workgroup needs to know about its tile, fetched with one scalar
 // load: with the slice widths in hand every wavefront derives the addresses of
 // all its slices without a dependent descriptor load.
@@ -137,8 +147,11 @@ struct TiledHost {
 // problems of that many transcripts each (per-cell EM, single_cell.rs:139-160): tiles then
 // never mix reads of two problems.  `win_cap` (kWin or kWinWide) bounds the LDS window of a tile: sparse
 // stores get more reads per tile from a wider window (the kernels then keep one count-window copy).
+// `tile_rows` (a multiple of 64, <= kTileRows) caps the reads of a tile: small stores are cut finer so that
+// their tiles still cover the chip (tile_rows_for above).
 bool build_tiled_layout(const uint64_t *row_ptr, const uint32_t *tid, const float *as_prob,
                         const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
-                        TiledHost *out, const char **err, uint32_t problem_size = 0, uint32_t win_cap = kWin);
+                        TiledHost *out, const char **err, uint32_t problem_size = 0, uint32_t win_cap = kWin,
+                        uint32_t tile_rows = kTileRows);
 
 } // namespace oem

@@ -86,13 +86,13 @@ __device__ __forceinline__ uint32_t tile_kmax(uint32_t k0, uint32_t problem_size
 }
 
 __global__ __launch_bounds__(kLThreads) void k_next_cut(const uint32_t *__restrict__ skey, uint32_t n_rows,
-                                                        uint32_t problem_size, uint32_t win_cap,
+                                                        uint32_t problem_size, uint32_t win_cap, uint32_t tile_rows,
                                                         uint32_t *__restrict__ next)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const uint32_t kmax = tile_kmax(skey[i], problem_size, win_cap);
-    uint32_t lim = i + kTileRows;
+    uint32_t lim = i + tile_rows;
     if (lim > n_rows) lim = n_rows;
     // first index in (i, lim) whose key exceeds kmax, else lim
     uint32_t a = i + 1, b = lim;
@@ -507,7 +507,7 @@ int out_alloc(T **p, size_t n, uint64_t *acct)
 }
 
 template <typename WT>
-int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, const WT *w_in, WT **w_out, WT **r_w_out, bool *built)
+int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, uint32_t tile_rows, const WT *w_in, WT **w_out, WT **r_w_out, bool *built)
 {
     *built = false;
     const DeviceCsr &m = s->csr;
@@ -546,7 +546,7 @@ int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, const WT *
     // C
     uint32_t *next = iota; // reuse
     hipLaunchKernelGGL(k_next_cut, dim3((n_rows + kLThreads - 1) / kLThreads), dim3(kLThreads), 0, st, skey, n_rows,
-                       problem_size, win_cap, next);
+                       problem_size, win_cap, tile_rows, next);
     OEM_HIP(hipGetLastError());
     uint32_t *tile_start;
     const uint32_t cap = n_rows + 1; // every tile holds at least one read
@@ -667,14 +667,14 @@ int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, const WT *
 
 // Builds s->tiled from s->csr on the device.  *built = false (and nothing allocated that matters)
 // when this builder does not take the store; the caller then uses the host builder.
-int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, bool *built)
+int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_cap, uint32_t tile_rows, bool *built)
 {
     *built = false;
     const DeviceCsr &m = s->csr;
     if (m.wide_ptr || m.n_reads == 0 || m.n_reads >= (1ull << 31) || m.nnz >= (1ull << 32)) return OEM_OK;
     int rc;
-    if (m.w_is_f64) rc = build_impl<double>(s, problem_size, win_cap, m.w64, &s->tiled.w64, &s->tiled.r_w64, built);
-    else rc = build_impl<float>(s, problem_size, win_cap, m.w32, &s->tiled.w32, &s->tiled.r_w32, built);
+    if (m.w_is_f64) rc = build_impl<double>(s, problem_size, win_cap, tile_rows, m.w64, &s->tiled.w64, &s->tiled.r_w64, built);
+    else rc = build_impl<float>(s, problem_size, win_cap, tile_rows, m.w32, &s->tiled.w32, &s->tiled.r_w32, built);
     if (rc != OEM_OK || !*built) { // leave no half-built layout behind
         DeviceTiled &t = s->tiled;
         hipFree(t.tiles); hipFree(t.perm); hipFree(t.codes); hipFree(t.w32); hipFree(t.w64); hipFree(t.r_tid);

@@ -124,6 +124,16 @@ template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 10
 #ifndef OEM_WAVES_WORDS
 #define OEM_WAVES_WORDS 4
 #endif
+#ifndef OEM_WAVES_CODED
+#define OEM_WAVES_CODED 5
+#endif
+#ifndef OEM_COPIES
+#define OEM_COPIES 4
+#endif
+#ifndef OEM_MAX_COPY_SHIFT
+#define OEM_MAX_COPY_SHIFT 3
+#endif
+constexpr uint32_t kMaxCopyShift = OEM_MAX_COPY_SHIFT;
 template <typename WT, int kDict> constexpr int tile_sets()
 {
     return sizeof(WT) == 8 ? OEM_SETS_F64 : kDict == kWFused ? OEM_SETS_FUSED : kDict == kWBytes ? OEM_SETS_BYTES
@@ -131,7 +141,7 @@ template <typename WT, int kDict> constexpr int tile_sets()
 }
 template <typename WT, int kDict> constexpr int tile_min_waves()
 {
-    return sizeof(WT) == 8 ? 2 : (kDict == kWFused || kDict == kWBytes) ? 5 : kDict == kWWords ? OEM_WAVES_WORDS
+    return sizeof(WT) == 8 ? 2 : (kDict == kWFused || kDict == kWBytes) ? OEM_WAVES_CODED : kDict == kWWords ? OEM_WAVES_WORDS
                                                                            : (OEM_SETS_F32 > 2 ? 4 : 2);
 }
 __device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
@@ -192,7 +202,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
                                            const uint32_t *__restrict__ cbase, const TileDesc &td,
                                            const double *theta_l, double *cnt_l, double *den_l,
                                            const uint32_t *__restrict__ row_w_perm,
-                                           const uint32_t *__restrict__ ibase, const float *dict_l, uint32_t exp_mask)
+                                           const uint32_t *__restrict__ ibase, const float *dict_l, uint32_t exp_mask, uint32_t cs)
 {
     // weight of alignment j >= kCh of the lane's read (reload loops)
     auto w_at = [&](uint32_t j) -> double {
@@ -242,11 +252,11 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
     den_l[rl] = inv;
 
-    // The count window is kept in kCopies interleaved copies (entry c of copy p at
-    // (c * kCopies + p) * 8): lanes of different copies that add into the same
+    // The count window is kept in 1 << cs interleaved copies (entry c of copy p at
+    // ((c << cs) + p) * 8): lanes of different copies that add into the same
     // transcript hit different addresses (and adjacent banks), which divides the
-    // same-address serialisation of the LDS atomics by up to kCopies.
-    const uint32_t copy_off = (lane % kCopies) * 8u;
+    // same-address serialisation of the LDS atomics by up to the number of copies.
+    const uint32_t copy_off = (lane & ((1u << cs) - 1u)) * 8u;
     // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
     // share it, and 64 same-address LDS atomics would serialise: reduce across the
     // wavefront and let one lane add.
@@ -256,9 +266,9 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
             const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u << cs), sum);
         } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
+            lds_add_f64(lds_at(cnt_l, (off0 << cs) + copy_off), v0);      // em.rs:128-129
         }
     }
 #pragma unroll
@@ -266,14 +276,14 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
             const double v = x[k] * inv;
-            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
         }
     }
     for (uint32_t j = kCh; j < width; ++j) {
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
     }
 }
 
@@ -309,7 +319,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
                                            const uint32_t *__restrict__ row_w_perm, bool prefetch_next,
                                            const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width,
                                            const uint32_t *__restrict__ ibase, const uint32_t *__restrict__ next_i,
-                                           const float *dict_l, uint32_t exp_mask)
+                                           const float *dict_l, uint32_t exp_mask, uint32_t cs)
 {
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
@@ -359,16 +369,16 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
     const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
     den_l[rl] = inv;
-    const uint32_t copy_off = (lane % kCopies) * 8u;
+    const uint32_t copy_off = (lane & ((1u << cs) - 1u)) * 8u;
     {
         const uint32_t off0 = code_off<kDict>(code_half(lo.c[0], 0));
         const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
         const double v0 = x[0] * inv;
         if (__all(off0 == u)) {
             const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u * kCopies), sum);
+            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u << cs), sum);
         } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, off0 * kCopies + copy_off), v0);      // em.rs:128-129
+            lds_add_f64(lds_at(cnt_l, (off0 << cs) + copy_off), v0);      // em.rs:128-129
         }
     }
 #pragma unroll
@@ -376,7 +386,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
         if ((uint32_t)k < width) { // uniform
             const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
             const double v = x[k] * inv;
-            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
         }
     }
     // the first register set is done: the next slice's loads go out now, under the rest of this fold
@@ -387,7 +397,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
             if ((uint32_t)(k + kCh) < width) { // uniform
                 const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
                 const double v = lds_ld(theta_l, off) * (double)slice_w<kDict>(hi, k, dict_l) * inv;
-                if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+                if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
             }
         }
     }
@@ -395,7 +405,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
         const uint32_t cc = cbase[(j >> 1) * 64 + lane];
         const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
         const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, off * kCopies + copy_off), v);
+        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
     }
 }
 
@@ -448,6 +458,13 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6); // SGPR: slice control flow is scalar
+    // Copies of the count window: as many as the tile's window leaves room for in the kWinT * kCopies entries of
+    // cnt_l (a power of two, at most 1 << kMaxCopyShift).  A tile of a dense store spans few transcripts (C3: 1024
+    // reads are ~20 transcripts + the margins, a window of ~150 of the 512 entries), and those are the tiles whose
+    // lanes add into the same few entries: halving the copies (2 for 4) cost 21 % of the C3 pass, so the tiles that
+    // can take 8 (C3 pass 0.1492 -> 0.146-0.147 ms; 16 or 32 copies: the same, profiles/r04_notes.md).
+    uint32_t cs = 0;
+    while (cs < kMaxCopyShift && (td.win_len << (cs + 1)) <= kWinT * (uint32_t)kCopies) ++cs;
     constexpr uint32_t kWaves = kTileThreads / 64;
     constexpr uint32_t kPerWave = kTileSlices / kWaves; // slices per wavefront
     // A tile's slices come in descending width, so dealing them round-robin gives wavefront 0 the widest of every
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         for (uint32_t u = 0; u < kDictPer; ++u)
             if (tx + u * kTileThreads < (uint32_t)dict_entries<kDict>()) dict_l[tx + u * kTileThreads] = dict_v[u];
     }
-    for (uint32_t i = tx; i < td.win_len * kCopies; i += kTileThreads) cnt_l[i] = 0.0;
+    for (uint32_t i = tx; i < (td.win_len << cs); i += kTileThreads) cnt_l[i] = 0.0;
     for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreads) den_l[i] = 0.0;
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
     __syncthreads();
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         fold_first<WT, kCh, kCopies, kNT, kDict>(R[0], R[1], wid[0], wave, lane, w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64,
                                                  td, theta_l, cnt_l, den_l, row_w_perm, kLate0 != 0,
                                                  w + (size_t)woff[kLate0] * 64, codes + (size_t)coff[kLate0] * 64,
-                                                 wid[kLate0], iptr(0), iptr(kLate0), dict_l, exp_mask);
+                                                 wid[kLate0], iptr(0), iptr(kLate0), dict_l, exp_mask, cs);
     else if (kLate0 != 0)
         load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[kLate0] * 64, codes + (size_t)coff[kLate0] * 64, lane, wid[kLate0], iptr(kLate0));
     OEM_PROBE(6);
@@ -627,7 +644,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
                        codes + (size_t)coff[late != kNone ? late : 0] * 64, lane, wid[late != kNone ? late : 0], iptr(late != kNone ? late : 0));
         if (s < td.n_slices)
             fold_slice<WT, kCh, kCopies, kDict>(R[set_of(q)], wid[q], s, lane, w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, td,
-                       theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l, exp_mask);
+                       theta_l, cnt_l, den_l, row_w_perm, iptr(q), dict_l, exp_mask, cs);
         OEM_PROBE(6 + q); // wave 0's slice q folded (its operands had to land first)
     }
     __syncthreads();
@@ -648,10 +665,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
 
     // ---- flush the window: consecutive lanes -> consecutive addresses ---------------
+    // (a thread starts at copy `lane` of its entry: the lanes of a wavefront then read different banks)
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         double v = 0.0;
-#pragma unroll
-        for (int p = 0; p < kCopies; ++p) v += cnt_l[i * kCopies + p];
+        for (uint32_t p = 0; p < (1u << cs); ++p) v += cnt_l[(i << cs) + ((p + lane) & ((1u << cs) - 1u))];
         if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
     OEM_PROBE(11); // queue stores and window flush issued
@@ -738,7 +755,7 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), 4, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), OEM_COPIES, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
 }

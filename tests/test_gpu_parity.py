@@ -1335,3 +1335,46 @@ def test_host_store_uploads_again_when_the_reference_would_see_new_data():
     with pytest.raises(ValueError):
         store.device_store(st.n_txps).bootstrap(2, init=np.ones(st.n_txps - 1))
     store.invalidate_device()
+
+
+@pytest.mark.parametrize("coverage", [False, True])
+@pytest.mark.parametrize("tile_rows", [64, 256, 1024])
+def test_reads_per_tile_do_not_change_the_answer(tile_rows, coverage):
+    """Small stores are cut into 256-read tiles (oem_layout.h: tile_rows_for), large ones into 1024-read tiles --
+    one slice per wavefront against four, with late slices and the hand-over of register sets.  The same 90 k-read
+    store laid out with 64, 256 and 1024 reads per tile (OEM_TILE_ROWS, test-only library): one pass with
+    multiplicities, the EM run, batched and row-weighted bootstraps against the oracle; the two builders agree."""
+    import os
+    from oarfish_amd import _lib
+    st = synth.make_store(90_000, 7_000, seed=611, coverage=coverage)
+    T = st.n_txps
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T)
+    rng = np.random.default_rng(tile_rows)
+    theta = rng.lognormal(0, 1.5, T)
+    w = rng.poisson(1.0, st.n_reads).astype(np.uint32)
+    want_m = c_oracle.m_step(o, theta, row_w=w)
+    want, wi = c_oracle.do_em(o, max_iter=120, conv_thresh=1e-3)
+    want_w, _ = c_oracle.do_em(o, max_iter=50, conv_thresh=0.0, row_w=w)
+    prev = os.environ.get("OEM_TILE_ROWS")
+    os.environ["OEM_TILE_ROWS"] = str(tile_rows)
+    try:
+        with _lib.testing(), DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T) as d:
+            n_tiles = d.info(_lib.OEM_INFO_TILES)
+            assert n_tiles >= (st.n_reads + tile_rows - 1) // tile_rows
+            assert (n_tiles <= 2 * (st.n_reads // tile_rows + 1)) or tile_rows == 1024
+            assert_counts_close(d.m_step(theta, w), want_m, st.n_reads, T, 1e-10, f"m-step, {tile_rows} reads per tile")
+            got, gi = d.em_run(None, 120, 1e-3, 50)
+            assert gi.niter == wi.niter
+            assert_counts_close(got, want, st.n_reads, T, 1e-9, f"em, {tile_rows} reads per tile")
+            got_w, _ = d.bootstrap(5, row_w_all=np.tile(w, (5, 1)), max_iter=50, conv_thresh=0.0)
+            for b in range(5):
+                assert_counts_close(got_w[b], want_w, st.n_reads, T, 1e-9, f"resampled {b}, {tile_rows} reads per tile")
+        h_host = _layout_hash(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T, host_build=True)
+        h_dev = _layout_hash(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T)
+        diff = [f for f, a, b in zip(LAYOUT_FIELDS, h_dev, h_host) if a != b and f != "built_on_device"]
+        assert not diff and h_host[0] == n_tiles, (diff, h_host[0], n_tiles)
+    finally:
+        if prev is None:
+            os.environ.pop("OEM_TILE_ROWS", None)
+        else:
+            os.environ["OEM_TILE_ROWS"] = prev
