@@ -70,6 +70,16 @@ constexpr int kBCh = 8;            // local alignments per read kept in register
 constexpr int kTileThreadsE = 512; // 8 wavefronts, 2 slices each
 constexpr int kRemE = 3;           // remote alignments per thread kept in registers
 constexpr int kFoldThreadsB = 1024;
+// Count window of k_em_tile_e: [c][copy][b].  The rotated slot order makes the four slots of an entry four
+// addresses; lanes l and l + 4 k still meet on one.  The 14 KiB that two 64 KiB workgroups leave of a CU's LDS hold
+// further copies for the tiles whose window is short enough (a dense store's tiles: few transcripts, the ones whose
+// lanes add into the same entries).  The theta window and the count copies share one pool of 46 KiB -- theta takes
+// what the tile's window needs, the copies the rest: 8 copies up to 163 window entries, 4 up to 294, 2 up to 490;
+// lane l adds into copy (l >> 2) mod copies.  (k_em_tile: 2 count-window copies instead of 4 cost 21 % of its
+// pass; here 1 -> 2 | 4 copies took 6 % off the batched pass, profiles/r04_notes.md.)
+constexpr uint32_t kPoolE = 5888; // 46 KiB: theta + counts 46 + denominators 32 = 78 KiB per workgroup
+constexpr uint32_t kMaxCopyShiftE = 3;
+static_assert(kPoolE >= 2 * kWin * kEB, "theta and one copy of the widest window must fit");
 static_assert(kB % kEB == 0 && kE >= 1, "kBatch must be a multiple of the epoch width");
 static_assert((kB & (kB - 1)) == 0 && kB <= 16, "row multiplicities are packed kB bytes per read");
 
@@ -162,7 +172,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
                                              const uint32_t *__restrict__ cbase, const double *theta_l, double *cnt_l,
                                              double *den_l, const uint32_t (&rot8)[kEB], uint32_t act_e, bool load_next,
                                              const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c,
-                                             uint32_t next_width, uint32_t exp_mask)
+                                             uint32_t next_width, uint32_t exp_mask, uint32_t cs, uint32_t cpy)
 {
     constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
     // Every use of the slice's registers stays below this point: without the pins the compiler hoists the
@@ -231,7 +241,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
                 const double v = wk * inv[j]; // (theta is multiplied in when the window is flushed)
-                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);                 // em.rs:128-129
+                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, (off << cs) + cpy + rot8[j]), v);    // em.rs:128-129
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -247,7 +257,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
                 for (int j = 0; j < kEB; ++j) {
                     const double v = wk * inv[j];
-                    if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off + rot8[j]), v);
+                    if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, (off << cs) + cpy + rot8[j]), v);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +273,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
                 const double v = wk * inv[j];
-                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, off4[m] + rot8[j]), v);
+                if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, (off4[m] << cs) + cpy + rot8[j]), v);
             }
         }
     }
@@ -313,8 +323,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     constexpr uint32_t exp_mask = 0u;
 #endif
 
-    __shared__ double theta_l[kWin * kEB];
-    __shared__ double cnt_l[kWin * kEB];
+    __shared__ double pool_l[kPoolE]; // theta window [win_len][kEB], then the count copies [win_len][copies][kEB]
     __shared__ double den_l[kEB * kTileRows];
 
     constexpr uint32_t kWaves = kTileThreadsE / 64;
@@ -411,6 +420,11 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     uint32_t rot8[kEB]; // byte offset of that slot inside a [c][b] window entry
 #pragma unroll
     for (int j = 0; j < kEB; ++j) rot8[j] = ((j + lane) & (kEB - 1)) * 8u;
+    uint32_t cs = 0; // copies of the count window = 1 << cs (wave-uniform), this lane's at byte cpy of an entry
+    while (cs < kMaxCopyShiftE && td.win_len * kEB * (1u + (2u << cs)) <= kPoolE) ++cs;
+    double *const theta_l = pool_l;
+    double *const cnt_l = pool_l + td.win_len * kEB;
+    const uint32_t cpy = ((lane >> 2) & ((1u << cs) - 1u)) * (kEB * 8u);
 
 #pragma unroll 1
     for (int e = 0; e < kE; ++e) {
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE)
                 theta_l[i] = th(theta[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], i % kEB);
         }
-        for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) cnt_l[i] = 0.0;
+        for (uint32_t i = tx; i < ((td.win_len * kEB) << cs); i += kTileThreadsE) cnt_l[i] = 0.0;
         for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreadsE) {
 #pragma unroll
             for (int b = 0; b < kEB; ++b) den_l[b * kTileRows + i] = 0.0;
@@ -498,14 +512,14 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             if (s0 < td.n_slices)
                 fold_slice_e<WT, kNT, true>(R[0], R[1], wid[0], mult[0], s0 * 64 + lane, lane, w + (size_t)woff[0] * 64,
                                             codes + (size_t)coff[0] * 64, theta_l, cnt_l, den_l, rot8, act_e, true,
-                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1], exp_mask);
+                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1], exp_mask, cs, cpy);
             else
                 load_slice_b<kNT, WT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
             OEM_PROBE_E(6);
             if (s1 < td.n_slices)
                 fold_slice_e<WT, kNT, false>(R[0], R[0], wid[1], mult[1], s1 * 64 + lane, lane, w + (size_t)woff[1] * 64,
                                              codes + (size_t)coff[1] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
-                                             nullptr, nullptr, 0u, exp_mask);
+                                             nullptr, nullptr, 0u, exp_mask, cs, cpy);
             OEM_PROBE_E(7);
         } else {
 #pragma unroll 1
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
                     }
                 fold_slice_e<WT, kNT, false>(cur, cur, width, mq, s * 64 + lane, lane, w + (size_t)wo * 64,
                                              codes + (size_t)co * 64, theta_l, cnt_l, den_l, rot8, act_e, false, nullptr,
-                                             nullptr, 0u, exp_mask);
+                                             nullptr, 0u, exp_mask, cs, cpy);
             }
         }
         __syncthreads();
@@ -559,7 +573,9 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         }
         // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b], theta multiplied in here --------
         for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) {
-            const double v = cnt_l[i] * theta_l[i];
+            double sum = 0.0;
+            for (uint32_t p = 0; p < (1u << cs); ++p) sum += cnt_l[((((i / kEB) << cs) + p) * kEB) + (i % kEB)];
+            const double v = sum * theta_l[i];
             if (v != 0.0) unsafeAtomicAdd(&cnt[((size_t)td.lo + i / kEB) * kB + eoff + (i % kEB)], v);
         }
         OEM_PROBE_E(9);
