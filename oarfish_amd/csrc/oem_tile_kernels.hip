@@ -130,6 +130,9 @@ template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 10
 #ifndef OEM_COPIES
 #define OEM_COPIES 4
 #endif
+#ifndef OEM_CNT_ENTRIES
+#define OEM_CNT_ENTRIES 0 // entries of the narrow-window count pool (0: kWin * OEM_COPIES)
+#endif
 #ifndef OEM_MAX_COPY_SHIFT
 #define OEM_MAX_COPY_SHIFT 3
 #endif
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 {
     __shared__ float dict_l[dict_entries<kDict>()]; // the distinct weights of a coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWideLds with one count-window copy (sparse stores)
-    __shared__ double cnt_l[kWinT * kCopies];
+    constexpr uint32_t kCntEntries = (kCopies > 1 && OEM_CNT_ENTRIES) ? OEM_CNT_ENTRIES : kWinT * (uint32_t)kCopies;
+    __shared__ double cnt_l[kCntEntries];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
 
     OEM_PROBE(0);
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // lanes add into the same few entries: halving the copies (2 for 4) cost 21 % of the C3 pass, so the tiles that
     // can take 8 (C3 pass 0.1492 -> 0.146-0.147 ms; 16 or 32 copies: the same, profiles/r04_notes.md).
     uint32_t cs = 0;
-    while (cs < kMaxCopyShift && (td.win_len << (cs + 1)) <= kWinT * (uint32_t)kCopies) ++cs;
+    while (cs < kMaxCopyShift && (td.win_len << (cs + 1)) <= kCntEntries) ++cs;
     constexpr uint32_t kWaves = kTileThreads / 64;
     constexpr uint32_t kPerWave = kTileSlices / kWaves; // slices per wavefront
     // A tile's slices come in descending width, so dealing them round-robin gives wavefront 0 the widest of every
