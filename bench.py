@@ -56,6 +56,8 @@ def parse(argv=None):
                          "over 8 GPUs, 16 otherwise)")
     ap.add_argument("--cell-reads", type=int, default=None, help="reads per cell (default 50000; tiny: 2000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="do not bind the process to the CPUs of the GPU's NUMA node (see bind_to_gpu_numa_node)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path even with one rank (1-GPU self test of that path)")
@@ -237,6 +239,29 @@ def hbm_traffic(workload):
     return None, None, None
 
 
+def bind_to_gpu_numa_node(torch, device):
+    """Run this process on the CPUs next to its GPU, as `numactl --cpunodebind` in a launcher would: the caller-side
+    arrays are pageable host memory, first touched by the thread that fills them, and the boundary copies them over
+    PCIe -- from the GPU's own NUMA node at ~35-55 GB/s, from the other socket at a third of that (the per-cell leg of
+    one box in three took 0.95-1.0 s instead of 0.70: 2.25 GB up, 0.3 GB back).  Returns what was done, for the line."""
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(f"{base}/numa_node").read().strip())
+        cpus = set()
+        for part in open(f"{base}/local_cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if node < 0 or not cpus:
+            return dict(bound=False, reason="no NUMA node reported for " + bdf)
+        os.sched_setaffinity(0, cpus)
+        return dict(bound=True, pci=bdf, numa_node=node, cpus=len(cpus))
+    except Exception as e:  # pragma: no cover  (no sysfs, no such attribute: run unbound)
+        return dict(bound=False, reason=repr(e))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,6 +290,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: oarfish_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    host_binding = dict(bound=False, reason="--no-numa-bind") if args.no_numa_bind else bind_to_gpu_numa_node(torch, local_rank)
     if dist_mode:
         if args.same_device:
             dist.init_process_group("gloo")
@@ -426,6 +452,7 @@ def main():
                        "parallelism": f"row-shard x{world} (nnz-balanced)" + (" [forced dist path]" if args.force_dist and world == 1 else "")
                                       + (" [all ranks on ONE device: self test, not scaling]" if args.same_device else ""),
                        "gen_s": round(t_gen, 2), "upload_s": round(t_up, 3), "runtime_init_s": round(t_first, 3),
+                       "host_binding": host_binding,
                        "device_ms_per_step": dev_ms / args.steps, "exchange": exchange},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -597,6 +624,8 @@ def cells_leg(args, n_cells, rank, world, local_rank, sync, max_over_ranks):
         _c0, _c1, out, infos = odist.em_cells_sharded(cell_off, row_ptr, tid, p, None, T, 0, 1, device=local_rank)
         torch.cuda.synchronize()
         tc = time.perf_counter() - t0
+        if os.environ.get("OEM_VERBOSE"):
+            print(f"[bench] cells leg: em_cells_sharded {tc * 1e3:.1f} ms", file=sys.stderr)
         passes = [i.n_passes for i in infos]
         mass = float(np.abs(out.sum(axis=1) - per_cell).max())
         # roofline of the batched EM loop: every pass of a cell streams that cell's matrix once (SURVEY.md 8d

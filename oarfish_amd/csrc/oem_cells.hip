@@ -282,7 +282,9 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
     if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_em_run_cells: tid/as_prob is NULL");
     t_cells_loop_ms = 0.0;
     t_cells_batched_passes = 0;
+    StageTimer tm_all;
     OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps)); // all cells at once, on several host threads
+    tm_all.lap("cells: range checks");
     // a read with a NaN coverage probability is dropped (em.rs:115), on every path below: the batched
     // groups create their stores directly, not through oem_store_create
     std::vector<double> cov_fixed;
@@ -363,6 +365,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         }
         work(0);
     }
+    tm_all.lap("cells: all groups");
     t_cells_loop_ms = timing.loop_ms;
     t_cells_batched_passes = timing.passes;
     for (int wk = 0; wk < kMaxWorkers; ++wk)
