@@ -152,6 +152,7 @@ void free_store(oem_store *s)
     }
     hipFree(s->multi.state); hipFree(s->multi.out); hipFree(s->multi.n_unfinished);
     hipFree(s->multi.live_tiles); hipFree(s->multi.live_buckets); hipFree(s->multi.d_live_counts);
+    hipFree(s->multi.rank);
     hipFree(s->theta);
     hipFree(s->cnt);
     hipFree(s->d_state);
@@ -226,6 +227,71 @@ __global__ __launch_bounds__(256) void k_relabel_cells(const uint32_t *__restric
     for (uint32_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) tid[j] += add;
 }
 
+// ---- per-cell transcript compaction --------------------------------------------------------------------------
+// A cell's reads touch a fraction of the annotation (single_cell.rs:139-160 runs every cell over ALL transcripts;
+// the ones no alignment of the cell names keep count 0 from the first iteration on and take no part in a
+// denominator or in the stopping rule -- em.rs:195-199 skips them once their abundance is 0, and at the first
+// iteration their (0 - avg) / avg = -1 loses against the 0 the maximum starts from).  So a cell's transcript
+// space in the batched store is the list of transcripts that OCCUR in it, in id order: windows span fewer ids
+// (fuller tiles), and the per-pass sweep over counts and abundances shrinks with the list.  Every cell gets
+// txps_eff = the longest list's length (uniform problem size: nothing else in the kernels changes); the results
+// are expanded to the caller's [cell][transcript] on the way out.
+__device__ __forceinline__ uint32_t cell_of_read(const unsigned long long *__restrict__ cell_row_off, uint32_t n_cells, uint64_t r)
+{
+    uint32_t a = 0, b = n_cells; // last cell whose first read is <= r
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (cell_row_off[m] <= r) a = m;
+        else b = m;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_cells_mark(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tid,
+                                                    const unsigned long long *__restrict__ cell_row_off, uint32_t n_cells,
+                                                    uint32_t cell_txps, uint64_t n_reads, uint32_t *__restrict__ rank)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const size_t base = (size_t)cell_of_read(cell_row_off, n_cells, r) * cell_txps;
+    for (uint32_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) rank[base + tid[j]] = 1u; // (same value from every writer)
+}
+
+// one workgroup per cell: flags -> exclusive ranks (kNoRank for the transcripts that do not occur), count of the cell
+constexpr int kRankT = 1024;
+__global__ __launch_bounds__(kRankT) void k_cells_rank(uint32_t *__restrict__ rank, uint32_t cell_txps, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t part[kRankT];
+    uint32_t *rk = rank + (size_t)blockIdx.x * cell_txps;
+    const uint32_t per = (cell_txps + kRankT - 1) / kRankT;
+    const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < cell_txps ? i0 + per : cell_txps;
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += rk[i];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < kRankT; d <<= 1) { // inclusive scan (Hillis-Steele)
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t o = part[threadIdx.x] - mine;
+    for (uint32_t i = i0; i < i1; ++i) rk[i] = rk[i] ? o++ : kNoRank;
+    if (threadIdx.x == kRankT - 1) counts[blockIdx.x] = part[kRankT - 1];
+}
+
+__global__ __launch_bounds__(256) void k_cells_relabel_ranked(const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ tid,
+                                                              const unsigned long long *__restrict__ cell_row_off, uint32_t n_cells,
+                                                              uint32_t cell_txps, uint32_t txps_eff, uint64_t n_reads,
+                                                              const uint32_t *__restrict__ rank)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t c = cell_of_read(cell_row_off, n_cells, r);
+    const size_t base = (size_t)c * cell_txps;
+    for (uint32_t j = row_ptr[r]; j < row_ptr[r + 1]; ++j) tid[j] = c * txps_eff + rank[base + tid[j]];
+}
+
 
 
 } // namespace
@@ -242,7 +308,7 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
     OEM_TRY(create_store_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, opts, s, relabel));
     StageTimer tm;
     // (the test-only library keeps the builders' streams when asked to: the layout tests hash them)
-    OEM_TRY(pack_remote_records(s, opts ? opts->problem_size : 0u, knob("OEM_KEEP_UNPACKED", 0) != 0));
+    OEM_TRY(pack_remote_records(s, s->multi.txps_eff ? s->multi.txps_eff : (opts ? opts->problem_size : 0u), knob("OEM_KEEP_UNPACKED", 0) != 0));
     tm.lap("slot table + packed records");
     if (!opts || opts->weight_coding == 0) {
         OEM_TRY(build_weight_dictionary(s)); // <= 256 distinct f32 weights: one byte per local alignment
@@ -307,11 +373,17 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
             OEM_TRY(dev_alloc(&m.w32, nnz, &s->hbm_bytes));
             OEM_HIP(hipMemcpy(m.w32, as_prob, sizeof(float) * nnz, hipMemcpyHostToDevice));
         }
-        OEM_TRY(dev_alloc(&s->theta, n_txps, &s->hbm_bytes));
-        OEM_TRY(dev_alloc(&s->cnt, n_txps, &s->hbm_bytes));
+        return OEM_OK;
+    };
+    // the vectors over the transcripts: after the upload, when a per-cell batch knows how many it keeps per cell
+    // (a per-cell batch reads its results from its own buffer: no pinned staging vector of 300 MB for it)
+    auto alloc_vectors = [&]() -> int {
+        const uint32_t T = m.n_txps;
+        OEM_TRY(dev_alloc(&s->theta, T, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&s->cnt, T, &s->hbm_bytes));
         OEM_TRY(dev_alloc(&s->d_state, 1, &s->hbm_bytes));
         OEM_HIP(hipHostMalloc((void **)&s->h_state, sizeof(EmState), hipHostMallocDefault));
-        OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (n_txps ? n_txps : 1), hipHostMallocDefault));
+        OEM_HIP(hipHostMalloc((void **)&s->h_pinned, sizeof(double) * (T && !relabel ? T : 1), hipHostMallocDefault));
         return OEM_OK;
     };
     s->global_n_reads = n_reads;
@@ -321,6 +393,7 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
     const uint32_t reorder = opts ? opts->reorder_rows : 0;
     if (reorder == 1 || n_reads == 0) {
         OEM_TRY(upload_csr());
+        OEM_TRY(alloc_vectors());
         tm.lap("caller-order CSR upload");
         return OEM_OK;
     }
@@ -339,9 +412,14 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
     uint32_t tile_rows = (uint32_t)knob("OEM_TILE_ROWS", relabel || (opts && opts->problem_size) ? kTileRows : tile_rows_for(n_reads));
     tile_rows = tile_rows < 64u ? 64u : tile_rows > kTileRows ? kTileRows : (tile_rows & ~63u);
     // host copy of the relabelled transcript ids, only for the host builder
+    bool relabelled_on_device = false;
     std::vector<uint32_t> vt;
     auto host_tids = [&]() -> const uint32_t * {
         if (!relabel) return tid;
+        if (vt.empty() && nnz && relabelled_on_device) { // (compacted ids: as the device wrote them)
+            vt.resize(nnz);
+            if (hipMemcpy(vt.data(), m.tid, sizeof(uint32_t) * nnz, hipMemcpyDeviceToHost) != hipSuccess) vt.clear();
+        }
         if (vt.empty() && nnz) {
             vt.resize(nnz);
             for (uint32_t c = 0; c < relabel->n_cells; ++c) {
@@ -351,19 +429,51 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
         }
         return vt.data();
     };
-    auto relabel_on_device = [&]() -> int {
+    uint32_t problem_size = opts ? opts->problem_size : 0u; // (a compacted per-cell batch: its own, below)
+    auto relabel_on_device = [&](bool compact) -> int {
         if (!relabel || nnz == 0) return OEM_OK;
         if (m.wide_ptr) return fail(OEM_ERR_ARG, "per-cell batch needs fewer than 2^32 alignments");
         unsigned long long *d_off = nullptr;
+        uint32_t *d_counts = nullptr;
         OEM_HIP(hipMalloc((void **)&d_off, sizeof(unsigned long long) * ((size_t)relabel->n_cells + 1)));
         hipError_t e = hipMemcpy(d_off, relabel->cell_row_off, sizeof(unsigned long long) * ((size_t)relabel->n_cells + 1),
                                  hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_relabel_cells, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s->stream,
+        const dim3 rgrid((uint32_t)((n_reads + 255) / 256));
+        const size_t n_rank = (size_t)relabel->n_cells * relabel->cell_txps;
+        if (e == hipSuccess && compact) {
+            // (see k_cells_mark: a cell keeps the transcripts that occur in it, every cell as many ids as the
+            // fullest one)
+            e = hipMalloc((void **)&s->multi.rank, sizeof(uint32_t) * n_rank);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_counts, sizeof(uint32_t) * relabel->n_cells);
+            if (e == hipSuccess) e = hipMemsetAsync(s->multi.rank, 0, sizeof(uint32_t) * n_rank, s->stream);
+            std::vector<uint32_t> counts(relabel->n_cells);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_cells_mark, rgrid, dim3(256), 0, s->stream, (const uint32_t *)m.row_ptr, m.tid, d_off,
+                                   relabel->n_cells, relabel->cell_txps, n_reads, s->multi.rank);
+                hipLaunchKernelGGL(k_cells_rank, dim3(relabel->n_cells), dim3(kRankT), 0, s->stream, s->multi.rank,
+                                   relabel->cell_txps, d_counts);
+                e = hipMemcpyAsync(counts.data(), d_counts, sizeof(uint32_t) * relabel->n_cells, hipMemcpyDeviceToHost, s->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            }
+            if (e == hipSuccess) {
+                uint32_t eff = 1;
+                for (uint32_t c : counts) eff = c > eff ? c : eff;
+                s->multi.txps_full = relabel->cell_txps;
+                s->multi.txps_eff = eff;
+                problem_size = eff;
+                m.n_txps = relabel->n_cells * eff;
+                hipLaunchKernelGGL(k_cells_relabel_ranked, rgrid, dim3(256), 0, s->stream, (const uint32_t *)m.row_ptr, m.tid,
+                                   d_off, relabel->n_cells, relabel->cell_txps, eff, n_reads, (const uint32_t *)s->multi.rank);
+                e = hipStreamSynchronize(s->stream);
+                relabelled_on_device = true;
+            }
+        } else if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_relabel_cells, rgrid, dim3(256), 0, s->stream,
                                (const uint32_t *)m.row_ptr, m.tid, d_off, relabel->n_cells, relabel->cell_txps, n_reads);
             e = hipStreamSynchronize(s->stream);
         }
         hipFree(d_off);
+        hipFree(d_counts);
         if (e != hipSuccess) return fail(OEM_ERR_HIP, "relabelling the cells failed: %s", hipGetErrorString(e));
         return OEM_OK;
     };
@@ -372,16 +482,18 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
     // with oem_store_opts.layout_build = 1.
     if (!(opts && opts->layout_build == 1)) {
         OEM_TRY(upload_csr());
-        OEM_TRY(relabel_on_device());
         tm.lap("caller-order CSR upload");
+        OEM_TRY(relabel_on_device(knob("OEM_CELLS_COMPACT_TXPS", 1) != 0));
+        OEM_TRY(alloc_vectors());
+        if (relabel) tm.lap("cells: transcripts relabelled");
         bool built = false;
-        OEM_TRY(build_tiled_layout_device(s, opts ? opts->problem_size : 0u, win_cap, tile_rows, &built));
+        OEM_TRY(build_tiled_layout_device(s, problem_size, win_cap, tile_rows, &built));
         tm.lap("tiled layout build (device)");
         if (built) return OEM_OK;
         TiledHost h;
         const char *err = nullptr;
-        if (build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, n_txps, &h, &err,
-                               opts ? opts->problem_size : 0u, win_cap, tile_rows)) {
+        if (build_tiled_layout(row_ptr, host_tids(), as_prob, cov_prob, n_reads, nnz, m.n_txps, &h, &err,
+                               problem_size, win_cap, tile_rows)) {
             OEM_TRY(upload_tiled(s, h));
         } else if (reorder == 2) {
             return fail(OEM_ERR_ARG, "oem_store_create: %s", err ? err : "cannot tile this store");
@@ -397,7 +509,8 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
             return;
         }
         csr_rc = upload_csr();
-        if (csr_rc == OEM_OK) csr_rc = relabel_on_device();
+        if (csr_rc == OEM_OK) csr_rc = relabel_on_device(false);
+        if (csr_rc == OEM_OK) csr_rc = alloc_vectors();
         if (csr_rc != OEM_OK) snprintf(csr_err, sizeof(csr_err), "%s", t_err); // t_err is thread-local
     });
     TiledHost h;

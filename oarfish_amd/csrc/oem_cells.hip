@@ -61,13 +61,23 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
     }
     *used = true;
     tm.lap("cells: store create");
+    // transcripts per cell IN THE STORE: the ones that occur in the cell, padded to the fullest cell's count
+    // (oem_api.hip: k_cells_mark); the caller's n_txps where the batch was not compacted
+    const uint64_t full_total = total_txps;
+    const bool compacted = s->multi.rank != nullptr;
+    if (compacted) n_txps = s->multi.txps_eff;
+    const uint64_t store_total = (uint64_t)n_cells * n_txps;
+    if (tm.on)
+        fprintf(stderr, "[oem] cells: %u transcripts per cell in the store (of %u), %u tiles, %llu local + %llu remote alignments\n",
+                n_txps, (unsigned)(full_total / n_cells), s->tiled.n_tiles, (unsigned long long)s->tiled.n_local,
+                (unsigned long long)s->tiled.n_remote);
 
     auto body = [&]() -> int {
         MultiBuffers &mb = s->multi;
         mb.n_problems = n_cells;
         mb.problem_size = n_txps;
         OEM_TRY(dev_alloc(&mb.state, n_cells, &s->hbm_bytes));
-        OEM_TRY(dev_alloc(&mb.out, (size_t)total_txps, &s->hbm_bytes));
+        OEM_TRY(dev_alloc(&mb.out, (size_t)store_total, &s->hbm_bytes));
         OEM_TRY(dev_alloc(&mb.n_unfinished, 1, &s->hbm_bytes));
         std::vector<BatchState> hs(n_cells);
         std::vector<uint64_t> reads(n_cells);
@@ -83,13 +93,13 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             if (hipMemcpyAsync(d_reads, reads.data(), sizeof(uint64_t) * n_cells, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
                 hipMemcpyAsync(mb.state, hs.data(), sizeof(BatchState) * n_cells, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
                 hipMemcpyAsync(mb.n_unfinished, &n_cells, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
-                hipMemsetAsync(s->cnt, 0, sizeof(double) * total_txps, s->stream) != hipSuccess) {
+                hipMemsetAsync(s->cnt, 0, sizeof(double) * store_total, s->stream) != hipSuccess) {
                 rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: upload of the per-cell state failed");
                 break;
             }
             if ((rc2 = launch_multi_init(s, s->theta, d_reads, mb)) != OEM_OK) break;
             EmParams p{n_txps, max_iter, 50u /* em::em, single_cell.rs:150 */, conv_thresh};
-            if (hipMemsetAsync(mb.out, 0, sizeof(double) * total_txps, s->stream) != hipSuccess) {
+            if (hipMemsetAsync(mb.out, 0, sizeof(double) * store_total, s->stream) != hipSuccess) {
                 rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: clearing the result buffer failed");
                 break;
             }
@@ -155,7 +165,23 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             hipEventDestroy(ev1);
             if (rc2 != OEM_OK) break;
             tm.lap("cells: EM loop");
-            if (hipMemcpy(out, mb.out, sizeof(double) * total_txps, hipMemcpyDeviceToHost) != hipSuccess ||
+            const double *d_res = mb.out;
+            double *d_full = nullptr;
+            if (compacted) { // expand to the caller's [cell][transcript] (the queue is done with: its memory is free by now)
+                if (hipMalloc((void **)&d_full, sizeof(double) * full_total) != hipSuccess) {
+                    rc2 = fail(OEM_ERR_OOM, "oem_em_run_cells: no device memory for the expanded results");
+                    break;
+                }
+                if ((rc2 = launch_multi_expand(s, mb, d_full)) != OEM_OK || hipStreamSynchronize(s->stream) != hipSuccess) {
+                    hipFree(d_full);
+                    if (rc2 == OEM_OK) rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: expanding the results failed");
+                    break;
+                }
+                d_res = d_full;
+            }
+            const bool copied = hipMemcpy(out, d_res, sizeof(double) * full_total, hipMemcpyDeviceToHost) == hipSuccess;
+            hipFree(d_full);
+            if (!copied ||
                 hipMemcpy(hs.data(), mb.state, sizeof(BatchState) * n_cells, hipMemcpyDeviceToHost) != hipSuccess) {
                 rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: result read-back failed");
                 break;

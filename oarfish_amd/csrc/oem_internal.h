@@ -188,7 +188,14 @@ struct MultiBuffers {
     uint32_t *d_live_counts = nullptr; // device: {n_live_tiles, n_live_buckets}
     uint32_t n_live_tiles = 0, n_live_buckets = 0; // host copies: the grids of the next launches
     bool live_valid = false;
+    // Per-cell transcript compaction (oem_api.hip: compact_cells): a cell's transcripts are renumbered to the rank of
+    // each among the transcripts that occur in the cell, and every cell owns txps_eff (= the largest such count)
+    // consecutive ids of the store.  rank[c * txps_full + t] = rank of transcript t in cell c, or kNoRank.
+    uint32_t *rank = nullptr;  // [n_problems * txps_full], device; NULL: no compaction (ids are c * T + t)
+    uint32_t txps_full = 0;    // the caller's n_txps
+    uint32_t txps_eff = 0;     // transcripts per cell in the store
 };
+constexpr uint32_t kNoRank = 0xffffffffu;
 
 struct Comm; // oem_comm.cpp
 
@@ -249,6 +256,7 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
 
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
+int launch_multi_expand(oem_store *s, const MultiBuffers &mb, double *full /* [n_problems * txps_full] */);
 int launch_multi_fold_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int launch_multi_reldiff(oem_store *s, double *theta, double *cnt, const MultiBuffers &mb, EmParams p);
 int multi_compact_live(oem_store *s, MultiBuffers &mb); // rebuilds the live lists (synchronises the stream)

@@ -16,13 +16,24 @@ namespace {
 constexpr int kMT = 256;
 
 // theta[p*T + i] = reads(p) / T   (em.rs:165 with the cell's own store.len())
+// (T: transcripts per cell in the store; T_full: the caller's n_txps -- the reference's store.len() / n_txps, whatever
+// the store keeps of the cell's transcripts)
 __global__ __launch_bounds__(kMT) void k_multi_init(double *__restrict__ theta,
-                                                    const uint64_t *__restrict__ problem_reads, uint32_t T)
+                                                    const uint64_t *__restrict__ problem_reads, uint32_t T, uint32_t T_full)
 {
     const uint32_t p = blockIdx.y;
-    const double avg = (double)problem_reads[p] / (double)T;
+    const double avg = (double)problem_reads[p] / (double)T_full;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x)
         theta[(size_t)p * T + i] = avg;
+}
+
+__global__ __launch_bounds__(kMT) void k_multi_expand(const double *__restrict__ out_eff, const uint32_t *__restrict__ rank,
+                                                      uint32_t T_full, uint32_t T_eff, size_t n, double *__restrict__ full)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rank[i];
+        full[i] = r == kNoRank ? 0.0 : out_eff[(i / T_full) * T_eff + r];
+    }
 }
 
 // rel-diff / swap / clear of one cell per blockIdx.y (em.rs:194-207); FINAL cells park their counts
@@ -221,7 +232,21 @@ int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_rea
     const uint32_t T = mb.problem_size;
     uint32_t gx = (T + kMT - 1) / kMT;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_multi_init, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, d_problem_reads, T);
+    hipLaunchKernelGGL(k_multi_init, dim3(gx, mb.n_problems), dim3(kMT), 0, s->stream, theta, d_problem_reads, T,
+                       mb.txps_full ? mb.txps_full : T);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+// results of a compacted batch -> the caller's [cell][transcript]: a transcript that does not occur in the cell is 0
+int launch_multi_expand(oem_store *s, const MultiBuffers &mb, double *full)
+{
+    const size_t n = (size_t)mb.n_problems * mb.txps_full;
+    if (n == 0) return OEM_OK;
+    size_t g = (n + kMT - 1) / kMT;
+    if (g > 65535u * 16u) g = 65535u * 16u;
+    hipLaunchKernelGGL(k_multi_expand, dim3((uint32_t)g), dim3(kMT), 0, s->stream, (const double *)mb.out, (const uint32_t *)mb.rank,
+                       mb.txps_full, mb.txps_eff, n, full);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

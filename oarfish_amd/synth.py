@@ -181,11 +181,22 @@ def make_config(name: str, coverage: bool = False, seed_offset: int = 0, **over)
 
 
 def make_cells(n_cells: int, reads_per_cell: int, n_txps: int, kbar: float = 8.0,
-               seed: int = BASE_SEED + 5, expressed_frac: float = 0.1, first_cell: int = 0, threads: int = 1):
+               seed: int = BASE_SEED + 5, expressed_frac: Optional[float] = None, first_cell: int = 0, threads: int = 1):
     """C5: concatenated per-cell stores.  Cell c is a pure function of (seed, c), so ranks that each
-    generate a block of cells (``first_cell``) produce pieces of one experiment."""
+    generate a block of cells (``first_cell``) produce pieces of one experiment.
+
+    ``expressed_frac`` (None: every cell draws from all ``n_txps`` transcripts, the benchmark's workload): a cell
+    expresses a random subset of that fraction of the annotation -- its store is generated over the subset and mapped
+    back through the sorted subset ids, so genes stay runs of neighbouring ids (single-cell data: a cell touches a
+    few per cent to a fifth of the transcripts; what the per-cell transcript compaction of the batched store is for)."""
     def one(c):
-        return make_store(reads_per_cell, n_txps, kbar, seed=seed * 1000 + first_cell + c, threads=1)
+        cs = seed * 1000 + first_cell + c
+        if expressed_frac is None:
+            return make_store(reads_per_cell, n_txps, kbar, seed=cs, threads=1)
+        n_sub = min(n_txps, max(int(n_txps * expressed_frac), 8))
+        sub = np.sort(np.random.default_rng([cs, 0xCE11]).choice(n_txps, n_sub, replace=False)).astype(np.uint32)
+        st = make_store(reads_per_cell, n_sub, kbar, seed=cs, threads=1)
+        return SyntheticStore(st.row_ptr, sub[st.tid], st.as_prob, None, n_txps, None, None)
 
     if threads > 1 and n_cells > 1:
         with ThreadPoolExecutor(max_workers=threads) as ex:

@@ -1378,3 +1378,50 @@ def test_reads_per_tile_do_not_change_the_answer(tile_rows, coverage):
             os.environ.pop("OEM_TILE_ROWS", None)
         else:
             os.environ["OEM_TILE_ROWS"] = prev
+
+
+@pytest.mark.parametrize("compact", [1, 0])
+def test_sparse_cells_keep_only_the_transcripts_that_occur(compact, monkeypatch):
+    """Per-cell transcript compaction (oem_api.hip: k_cells_mark / k_cells_rank): the batched store gives a cell the
+    transcripts that occur in it, renumbered by rank, every cell as many ids as the fullest one; the results are
+    expanded to [cell][transcript] on the way out.  Cells that express disjoint 2-20 % slices of a 9 000-transcript
+    annotation, one cell without reads, one cell that touches everything: every cell against its own oracle run
+    (the transcripts a cell does not name are exactly 0), with the compaction and with the plain c * T + t ids."""
+    from oarfish_amd import _lib
+    T = 9_000
+    rng = np.random.default_rng(77)
+    parts = []
+    fracs = [0.02, 0.2, 0.05, None, 0.1, 1.0, 0.03]
+    for c, f in enumerate(fracs):
+        if f is None:                                    # a barcode without reads
+            parts.append((np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32)))
+            continue
+        n_sub = max(int(T * f), 8)
+        sub = np.sort(rng.choice(T, n_sub, replace=False)).astype(np.uint32)
+        st = synth.make_store(2_000 + 500 * c, n_sub, seed=700 + c, threads=1)
+        parts.append((st.row_ptr, sub[st.tid], st.as_prob))
+    cell_off = np.zeros(len(parts) + 1, np.uint64)
+    rps, base = [np.zeros(1, np.uint64)], 0
+    for c, (rp, _t, _p) in enumerate(parts):
+        rps.append(rp[1:] + np.uint64(base))
+        base += int(rp[-1])
+        cell_off[c + 1] = cell_off[c] + np.uint64(len(rp) - 1)
+    row_ptr = np.concatenate(rps)
+    tid = np.concatenate([t for _r, t, _p in parts])
+    p = np.concatenate([q for _r, _t, q in parts])
+    monkeypatch.setenv("OEM_CELLS_COMPACT_TXPS", str(compact))
+    with _lib.testing():
+        out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=200, convergence_thresh=1e-3)
+    assert out.shape == (len(parts), T)
+    for c, (rp, t, q) in enumerate(parts):
+        n = len(rp) - 1
+        if n == 0:
+            assert not out[c].any()
+            continue
+        o = c_oracle.Store(rp, t, q, None, T)
+        want, wi = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3, min_iter_gate=50)
+        absent = np.ones(T, bool)
+        absent[t] = False
+        assert not out[c][absent].any() and not want[absent].any()
+        assert abs(infos[c].niter - wi.niter) <= 1
+        assert_counts_close(out[c], want, n, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"cell {c}")
