@@ -40,7 +40,10 @@ namespace oem {
 constexpr uint32_t kTileRows = 1024;  // reads per tile (16 slices of 64)
 constexpr uint32_t kWin = 512;        // transcripts per tile window (2 x 4 KiB of LDS); 8*kWin must fit 16 bits
 constexpr uint32_t kWinWide = 2048;   // window cap of sparse stores as oem_store_opts.window_cap names it (few reads per transcript: per-cell batches)
-constexpr uint32_t kWinWideLds = 1984; // ... and what their tiles are cut for: theta + count window (2 x 15.5 KiB) + the per-read
+#ifndef OEM_WIN_WIDE_LDS
+#define OEM_WIN_WIDE_LDS 1984
+#endif
+constexpr uint32_t kWinWideLds = OEM_WIN_WIDE_LDS; // ... and what their tiles are cut for: theta + count window (2 x 15.5 KiB) + the per-read
                                        // denominators (8 KiB) + the 1 KiB weight table = 40 KiB, four workgroups per CU
 constexpr uint32_t kMargin = 64;      // window slack on both sides of the primaries
 constexpr uint32_t kBucket = 4096;    // transcripts per remote bucket (32 KiB of LDS; x 4 slots = 128 KiB in the batched bootstrap's fold)

@@ -124,6 +124,9 @@ template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 10
 #ifndef OEM_WAVES_WORDS
 #define OEM_WAVES_WORDS 4
 #endif
+#ifndef OEM_WAVES_WIDE
+#define OEM_WAVES_WIDE 2 // launch-bounds waves per SIMD of the wide-window kernel with f32 / coded weights
+#endif
 #ifndef OEM_WAVES_CODED
 #define OEM_WAVES_CODED 5
 #endif
@@ -755,7 +758,7 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     if (n_tiles == 0) return;
     const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, 2, 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, (sizeof(WT) == 4 ? OEM_WAVES_WIDE : 2), 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
     else
