@@ -365,6 +365,11 @@ def main():
                     kernel="k_em_tile + k_remote_fold (one E/M pass)", kernel_avg_ms=k_ms,
                     algorithmic_bytes_per_launch=alg_bytes, traffic_source=traffic_src, traffic_stale=traffic_stale,
                     frac_of_achievable=achieved / HBM_ACHIEVABLE_GBS, achievable_peak=HBM_ACHIEVABLE_GBS)
+    if traffic:
+        # the bytes the kernels actually moved (PMC passes of the same command) over the same duration: the rate of
+        # the memory system, next to the rate of the algorithmic bytes that `frac` is
+        roofline["traffic_gbs"] = traffic / (k_ms * 1e-3) / 1e9
+        roofline["frac_traffic"] = roofline["traffic_gbs"] / HBM_PEAK_GBS
     # The store's local weights are dictionary-coded when it has at most 256 distinct ones (as_prob is exp of an
     # integer score gap over a constant; the C3 store has 98): say so, and time the same pass on the plain f32
     # stream beside it (oem_store_opts.weight_coding = 1) so that both figures are on the line.
