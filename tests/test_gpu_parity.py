@@ -1425,3 +1425,27 @@ def test_sparse_cells_keep_only_the_transcripts_that_occur(compact, monkeypatch)
         assert not out[c][absent].any() and not want[absent].any()
         assert abs(infos[c].niter - wi.niter) <= 1
         assert_counts_close(out[c], want, n, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"cell {c}")
+
+
+@pytest.mark.parametrize("T,n_cells,reads,kmax,hot", [(1, 3, 200, 1, False), (3, 2, 500, 3, False), (70, 5, 1000, 6, False),
+                                                      (5000, 4, 3000, 8, True), (4097, 3, 2000, 5, False),
+                                                      (20000, 40, 300, 4, False)])
+def test_cells_of_odd_shapes_through_the_compacted_store(T, n_cells, reads, kmax, hot):
+    """One transcript, three transcripts, every read of a cell on the same two transcripts of 5 000, a transcript
+    count one past a bucket, forty small cells: the ranked transcript ids of the batched store (a cell keeps what
+    occurs in it) against the per-cell oracle."""
+    rng = np.random.default_rng(T * 31 + n_cells)
+    pool = min(T, 2) if hot else T
+    lens = np.minimum(rng.integers(1, kmax + 1, size=n_cells * reads), pool)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tid = np.concatenate([np.sort(rng.choice(pool, size=int(l), replace=False)) for l in lens]).astype(np.uint32)
+    p = np.exp(-rng.integers(0, 20, size=len(tid)) / 5.0).astype(np.float32)
+    cell_off = (np.arange(n_cells + 1) * reads).astype(np.uint64)
+    out, infos = oarfish_amd.em_cells(cell_off, rp, tid, p, None, T, max_iter=100, convergence_thresh=1e-3)
+    for c in range(n_cells):
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(rp[r0]), int(rp[r1])
+        o = c_oracle.Store(rp[r0:r1 + 1] - rp[r0], tid[a0:a1], p[a0:a1], None, T)
+        want, wi = c_oracle.do_em(o, max_iter=100, conv_thresh=1e-3, min_iter_gate=50)
+        assert abs(infos[c].niter - wi.niter) <= 1
+        assert_counts_close(out[c], want, reads, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"T={T} cell {c}")
