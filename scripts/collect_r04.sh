@@ -35,5 +35,8 @@ tail -3 $out/collect_c3.log; cat $out/boot_traffic.log $out/boot1.log $out/boot2
 # per-cell loop traffic (FETCH / WRITE in their own passes)
 sed 's/r03/r04/g' scripts/collect_cells_traffic.sh > /tmp/collect_cells_traffic_r04.sh; bash /tmp/collect_cells_traffic_r04.sh > $out/cells_traffic.log 2>&1
 cp gpurun_out/cells_traffic/r04_c5_cells625_hbm_traffic.json $out/ 2>/dev/null
+# SQ / TCC counters of the per-cell loop (averages over the loop's launches: the all-live passes and the thin tail)
+bash scripts/collect_pmc_cmd.sh $out/pmc_cells "k_em_tile|k_multi_fold_reldiff" -- python scripts/cells_bench.py 625 50000 60000 > /dev/null 2>&1
+cp $out/pmc_cells/summary.txt $out/r04_c5_cells625_pmc_summary.txt
 # cost attribution of the two tile kernels (test-only library)
 bash scripts/tile_exp.sh c3 2>/dev/null | grep -v amdgpu > $out/r04_tile_cost_attribution.txt
