@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
         for (uint32_t q = 0; q < kPerWave; ++q) {
             const uint32_t rl = slice_of(q) * 64 + lane;
-            mult[q] = rl < td.n_rows ? *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff) : 0u;
+            mult[q] = rl < td.n_rows ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff)) : 0u;
         }
         // multiplicities of the reads of this thread's remote records (4 KB per tile: cache-resident).  A read
         // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
                 for (int b = 0; b < kEB; ++b) qv[b] = wv * den_l[b * kTileRows + rrow[k]];
 #pragma unroll
-                for (int b = 0; b < kEB; ++b) qp[b] = qv[b];
+                for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(qv[b], &qp[b]);
             }
         }
         for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             double *qp = queue + (size_t)(sd_t[t >> kBucketShift] + i) * kB + eoff;
             const double wv = (double)r_w[o];
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) qp[b] = wv * den_l[b * kTileRows + row];
+            for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(wv * den_l[b * kTileRows + row], &qp[b]);
         }
         // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b], theta multiplied in here --------
         for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) {
@@ -628,8 +628,10 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
 #pragma unroll
         for (int k = 0; k < kFoldDepth; ++k) {
             const uint32_t oo = o + k * kEntriesPerStep, oc = oo < s1 ? oo : s1 - 1;
-            v[k] = *piece(oc);
-            d[k] = q_dst[oc];
+            const D2 *pp = piece(oc); // (read once: non-temporal, the window's theta and counts stay in the L2)
+            v[k].x = __builtin_nontemporal_load(&pp->x);
+            v[k].y = __builtin_nontemporal_load(&pp->y);
+            d[k] = __builtin_nontemporal_load(&q_dst[oc]);
         }
     };
     auto consume = [&](const D2 (&v)[kFoldDepth], const uint32_t (&d)[kFoldDepth], uint32_t o) {

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
     for (int k = 0; k < kRem; ++k) {
         const uint32_t i = tx + k * kTileThreads;
-        if (i < td.remote_cnt && !OEM_EXP(1u)) queue[rslot[k]] = rx[k] * den_l[rrow[k]];
+        if (i < td.remote_cnt && !OEM_EXP(1u)) __builtin_nontemporal_store(rx[k] * den_l[rrow[k]], &queue[rslot[k]]);
     }
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
