@@ -40,3 +40,6 @@ bash scripts/collect_pmc_cmd.sh $out/pmc_cells "k_em_tile|k_multi_fold_reldiff" 
 cp $out/pmc_cells/summary.txt $out/r04_c5_cells625_pmc_summary.txt
 # cost attribution of the two tile kernels (test-only library)
 bash scripts/tile_exp.sh c3 2>/dev/null | grep -v amdgpu > $out/r04_tile_cost_attribution.txt
+# gpurun copies back at most 64 MiB: the raw traces and counter tables stay on the box, the summaries travel
+find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete
+du -sh gpurun_out | tail -1
