@@ -105,8 +105,8 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t oo = o + k * kFT, oc = oo < q1 ? oo : q1 - 1;
-            v[k] = queue[oc];
-            d[k] = q_dst[oc];
+            v[k] = __builtin_nontemporal_load(&queue[oc]); // (read once: the abundances and counts keep the caches)
+            d[k] = __builtin_nontemporal_load(&q_dst[oc]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
