@@ -681,6 +681,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(11); // queue stores and window flush issued
 }
 
+// kNTQ: the queue range is read non-temporally.  Measured both ways (profiles/r04_notes.md): a store that fits the
+// Infinity Cache with room to spare (C2: 1 M reads) gains 2.7 % of its pass -- the entries are read once and theta and the
+// counts keep the L2 -- while at C3 the fold finds the entries the tile kernel has just written in the caches, and
+// reading past them costs 2.8 % (2.5 M reads: 1.6 %; 1.25 M: the same either way).
+template <bool kNTQ>
 __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
     const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, const EmState *state,
@@ -715,8 +720,8 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
 #pragma unroll
         for (int k = 0; k < kDepth; ++k) {
             const uint32_t oo = o + k * kFoldThreads, oc = oo < s1 ? oo : s1 - 1;
-            v[k] = queue[oc];
-            d[k] = q_dst[oc];
+            v[k] = ld_stream<kNTQ>(&queue[oc]);
+            d[k] = ld_stream<kNTQ>(&q_dst[oc]);
         }
 #pragma unroll
         for (int k = 0; k < kDepth; ++k)
@@ -832,9 +837,14 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     OEM_HIP(hipGetLastError());
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
         const uint32_t n_groups = fold_groups(t);
-        hipLaunchKernelGGL(k_remote_fold, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
-                           s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                           s->csr.n_txps, problems, problem_size);
+        if (stream_bytes > (96ull << 20)) // (2.5 M reads, 170 MB of streams: already better cached -- see kNTQ)
+            hipLaunchKernelGGL(k_remote_fold<false>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
+                               s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
+                               s->csr.n_txps, problems, problem_size);
+        else
+            hipLaunchKernelGGL(k_remote_fold<true>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
+                               s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
+                               s->csr.n_txps, problems, problem_size);
         OEM_HIP(hipGetLastError());
     }
     return OEM_OK;
