@@ -891,6 +891,35 @@ def test_full_size_c3_coverage_store_matches_oracle():
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["uniform_gaps_words16", "f32_stream"])
+def test_full_size_c3_other_weight_codings_match_oracle(kind):
+    """The C3-sized store through the two weight codings the default store does not take: long-read score gaps (514
+    distinct weights: 16-bit indices, 4 KiB table in LDS) and the plain f32 stream (weight_coding = 1) -- the kernels
+    behind `roofline.frac_uniform_gaps` and `roofline.frac_f32_stream`.  12 iterations against the multi-threaded oracle
+    on every transcript, mass conservation, and a batched-bootstrap replicate against the serial oracle."""
+    threads = min(32, os.cpu_count() or 8)
+    if kind == "f32_stream":
+        st, coding = synth.make_config("c3"), 1
+    else:
+        st, coding = synth.make_store(10_000_000, 200_000, 8.0, threads=threads, gaps="uniform"), 0
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, st.n_txps)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps, weight_coding=coding) as d:
+        n = d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
+        assert (n == 0) if coding else (256 < n <= 1024), n
+        cnt, info = d.em_run(None, 12, 0.0, 1)
+        assert info.niter == 12 and info.n_passes == 13
+        want, wi = c_oracle.em_par(o, max_iter=12, conv_thresh=0.0, min_iter_gate=1)
+        assert_counts_close(cnt, want, st.n_reads, st.n_txps, 1e-8, f"c3 {kind}, 12 iterations")
+        assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads
+        W = np.stack([d.bootstrap_weights(7, 0), np.ones(st.n_reads, dtype=np.uint32)])
+        bout, binfo = d.bootstrap(2, row_w_all=W, max_iter=6, conv_thresh=0.0)
+        wantb, _ = c_oracle.do_em(o, row_w=W[0], max_iter=6, conv_thresh=0.0)
+        assert binfo[0].niter == 6 and binfo[0].n_passes == 7
+        assert_counts_close(bout[0], wantb, st.n_reads, st.n_txps, 1e-8, f"c3 {kind}, batched bootstrap replicate")
+        assert abs(bout[1].sum() - st.n_reads) < 1e-7 * st.n_reads
+
+
+@pytest.mark.timeout(900)
 def test_c5_slice_of_one_gpu_properties():
     """BASELINE configs[4] at the size ONE GPU sees when 5 k cells are dealt to 8: 625 cells x 50 k reads (31 M reads,
     250 M alignments, one batched store: wide windows, fused fold, live-tile compaction).  No oracle at this size: per
