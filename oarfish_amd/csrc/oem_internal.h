@@ -254,6 +254,10 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
                          uint32_t problem_size = 0, bool skip_fold = false);
 
+// oem_tile_pipe.hip: the same pass as a software pipeline over tiles (persistent workgroups), for the stores it applies to
+bool tile_pipeline_applies(const oem_store *s, const BatchState *problems);
+int launch_tile_pipeline(oem_store *s, const double *theta, double *cnt, const EmState *state, const uint32_t *row_w_perm, bool nt);
+
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);
 int launch_multi_expand(oem_store *s, const MultiBuffers &mb, double *full /* [n_problems * txps_full] */);

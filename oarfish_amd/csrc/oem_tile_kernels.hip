@@ -16,6 +16,25 @@
 
 #include "oem_internal.h"
 
+// Phase timestamps of k_em_tile (test-only library): wave 0 of every workgroup stamps the device wall clock
+// (100 MHz) at its phase boundaries into g_tile_probe[tile][16] -- scripts/tile_probe.py turns them into the
+// per-phase account of profiles/r03_notes.md.  The product build has no probe code at all.
+// Cost attribution (test-only library, OEM_TILE_EXP): parts of the kernel switched off -- wrong results, the time
+// says what the part costs.  1 queue stores, 2 remote denominator atomics, 4 local scatter atomics, 8 local theta
+// reads, 16 remote theta gathers
+#ifdef OEM_TESTING
+#define OEM_PROBE(i)                                                                                          \
+    do {                                                                                                      \
+        if (g_tile_probe && threadIdx.x == 0) g_tile_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#define OEM_EXP(bit) ((exp_mask & (bit)) != 0u) // (exp_mask: g_tile_exp read once per kernel, an SGPR)
+#else
+#define OEM_PROBE(i) do { } while (0)
+#define OEM_EXP(bit) false
+#endif
+
+#include "oem_tile_common.h"
+
 namespace oem {
 
 namespace {
@@ -23,397 +42,10 @@ namespace {
 constexpr int kFoldThreads = 1024;
 constexpr uint32_t kFoldEntriesPerGroup = 2 * kBucket; // queue entries that repay a fold workgroup's window clear + flush
 
-// Phase timestamps of k_em_tile (test-only library): wave 0 of every workgroup stamps the device wall clock
-// (100 MHz) at its phase boundaries into g_tile_probe[tile][16] -- scripts/tile_probe.py turns them into the
-// per-phase account of profiles/r03_notes.md.  The product build has no probe code at all.
 #ifdef OEM_TESTING
 __device__ unsigned long long *g_tile_probe = nullptr;
-#define OEM_PROBE(i)                                                                                          \
-    do {                                                                                                      \
-        if (g_tile_probe && threadIdx.x == 0) g_tile_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
-    } while (0)
-// cost attribution (test-only library, OEM_TILE_EXP): parts of the kernel switched off -- wrong results, the time
-// says what the part costs.  1 queue stores, 2 remote denominator atomics, 4 local scatter atomics, 8 local theta
-// reads, 16 remote theta gathers
 __device__ unsigned int g_tile_exp = 0;
-#define OEM_EXP(bit) ((exp_mask & (bit)) != 0u) // (exp_mask: g_tile_exp read once per kernel, an SGPR)
-#else
-#define OEM_PROBE(i) do { } while (0)
-#define OEM_EXP(bit) false
 #endif
-
-__device__ __forceinline__ void lds_add_f64(double *p, double v)
-{
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_f64
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// The matrix streams (weights, codes, remote records) are touched once per pass; theta and the
-// tile descriptors are re-read all the time.  When the store is larger than the 256 MiB Infinity
-// Cache, non-temporal loads keep the once-only traffic from evicting theta from the 4 MiB L2 of
-// each XCD (its gathers are the L2-request-bound part of the kernel): C3 0.244 -> 0.226 ms.  A
-// store that fits the Infinity Cache (C2, or one shard of an 8-GPU run) is faster with ordinary
-// loads (0.0348 vs 0.0387 ms), so the policy is a template flag chosen per store.
-template <bool kNT, typename T>
-__device__ __forceinline__ T ld_stream(const T *p)
-{
-    return kNT ? __builtin_nontemporal_load(p) : *p;
-}
-
-// LDS window entries are addressed by byte offset (the 16-bit codes are stored
-// pre-multiplied by 8), which saves the shift per alignment.
-__device__ __forceinline__ double lds_ld(const double *base, uint32_t byte_off)
-{
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-__device__ __forceinline__ double *lds_at(double *base, uint32_t byte_off)
-{
-    return reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off);
-}
-
-// Registers of one SELL-64 slice for one lane: up to kCh local alignments
-// (longer reads spill to a reload loop); kRem = remote alignments per thread whose
-// theta*w stays in registers between the two remote phases.
-template <typename WT, int kCh>
-struct SliceRegs {
-    WT w[kCh];            // the weights themselves ...
-    uint32_t wi[kCh / 2]; // ... or (dictionary-coded stores, oem_layout_dict.hip) table indices: four one-byte ones per
-                          // word (kWBytes: kCh / 4 words) or two 16-bit ones per word (kWWords)
-    uint32_t c[kCh / 2];
-};
-// Weight coding of a store (oem_layout_dict.hip): 0 the f32 / f64 stream; 1 one-byte table indices in their own
-// stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
-// (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
-// no weight stream at all, a local alignment is its two code bytes; 3 WORDS: 16-bit indices, two per u32, stored in
-// the geometry of the window codes (257..1024 distinct weights -- long reads with score gaps in the hundreds).
-constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2, kWWords = 3;
-template <int kDict> constexpr int dict_entries() { return kDict == kWWords ? 1024 : kDict != kWPlain ? 256 : 1; }
-
-// Register sets and launch bound (waves per SIMD the compiler must leave room for) of k_em_tile by weight coding:
-// how many of a wavefront's slices sit in registers before the fold starts (see kSets in the kernel).  Measured
-// (profiles/r04_notes.md; C3 pass, two sets at five workgroups per CU before): fused / byte codes, 4 / 6 registers a
-// set: all five sets, still five workgroups per CU: 0.168 -> 0.150 ms; the f32 stream, 12 registers a set: five sets at
-// FOUR workgroups per CU: 0.196 -> 0.177 (four sets 0.181, three 0.186); 16-bit indices, 8 a set: five sets at four
-// workgroups 0.176 -> 0.166 (three sets at five: 0.170); f64 weights (coverage), 20 a set and four workgroups per CU
-// either way: three sets 0.248 -> 0.239; the wide-window kernel of the per-cell batches: no difference (two).
-// The defaults can be overridden per build for A/B (scripts/build_variant.sh).
-#ifndef OEM_SETS_FUSED
-#define OEM_SETS_FUSED 5
-#endif
-#ifndef OEM_SETS_BYTES
-#define OEM_SETS_BYTES 5
-#endif
-#ifndef OEM_SETS_WORDS
-#define OEM_SETS_WORDS 5
-#endif
-#ifndef OEM_SETS_F32
-#define OEM_SETS_F32 5
-#endif
-#ifndef OEM_SETS_F64
-#define OEM_SETS_F64 3
-#endif
-#ifndef OEM_SETS_WIDE
-#define OEM_SETS_WIDE 2
-#endif
-#ifndef OEM_WAVES_WORDS
-#define OEM_WAVES_WORDS 4
-#endif
-#ifndef OEM_WAVES_WIDE
-#define OEM_WAVES_WIDE 2 // launch-bounds waves per SIMD of the wide-window kernel with f32 / coded weights
-#endif
-#ifndef OEM_WAVES_CODED
-#define OEM_WAVES_CODED 5
-#endif
-#ifndef OEM_COPIES
-#define OEM_COPIES 4
-#endif
-#ifndef OEM_CNT_ENTRIES
-#define OEM_CNT_ENTRIES 0 // entries of the narrow-window count pool (0: kWin * OEM_COPIES)
-#endif
-#ifndef OEM_MAX_COPY_SHIFT
-#define OEM_MAX_COPY_SHIFT 3
-#endif
-constexpr uint32_t kMaxCopyShift = OEM_MAX_COPY_SHIFT;
-template <typename WT, int kDict> constexpr int tile_sets()
-{
-    return sizeof(WT) == 8 ? OEM_SETS_F64 : kDict == kWFused ? OEM_SETS_FUSED : kDict == kWBytes ? OEM_SETS_BYTES
-                                          : kDict == kWWords ? OEM_SETS_WORDS : OEM_SETS_F32;
-}
-template <typename WT, int kDict> constexpr int tile_min_waves()
-{
-    return sizeof(WT) == 8 ? 2 : (kDict == kWFused || kDict == kWBytes) ? OEM_WAVES_CODED : kDict == kWWords ? OEM_WAVES_WORDS
-                                                                           : (OEM_SETS_F32 > 2 ? 4 : 2);
-}
-__device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
-template <int kDict>
-__device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
-__device__ __forceinline__ uint32_t code_widx(uint32_t half) { return (half & 7u) | ((half >> 9) & 0x78u); }
-// weight of entry k of a register set: coded stores read it from the table in LDS (index 0 = 0.0: padded entries
-// and entries beyond the slice's width need no masking)
-template <int kDict, typename WT, int kCh>
-__device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const float *dict_l)
-{
-    if (kDict == kWBytes) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
-    if (kDict == kWWords) return (WT)dict_l[code_half(r.wi[k >> 1], k & 1)];
-    if (kDict == kWFused) return (WT)dict_l[code_widx(code_half(r.c[k >> 1], k & 1))];
-    return r.w[k];
-}
-
-// Issue every load of a slice before any use.  `wbase`/`cbase`/`width` are
-// wave-uniform (SGPRs), so the loads take the scalar-base + lane-offset form with
-// immediate offsets, and the width tests are scalar branches: no per-alignment
-// address arithmetic.  Pairs are loaded together; the second element of the last
-// pair of an odd-width slice is the next slice's first alignment (the arrays are
-// padded by one row) and is zeroed.
-template <typename WT, int kCh, bool kNT = false, int kDict = kWPlain>
-__device__ __forceinline__ void load_slice(SliceRegs<WT, kCh> &r, const WT *__restrict__ wbase,
-                                           const uint32_t *__restrict__ cbase, uint32_t lane,
-                                           uint32_t width, const uint32_t *__restrict__ ibase = nullptr)
-{
-#pragma unroll
-    for (int g = 0; g < kCh / 2; ++g) {
-        if ((uint32_t)(2 * g) < width) {
-            if (kDict == kWBytes) {
-                if ((g & 1) == 0) r.wi[g >> 1] = ld_stream<kNT>(&ibase[(g >> 1) * 64 + lane]);
-            } else if (kDict == kWWords) {
-                r.wi[g] = ld_stream<kNT>(&ibase[g * 64 + lane]);
-            } else if (kDict == kWPlain) {
-                r.w[2 * g] = ld_stream<kNT>(&wbase[(2 * g) * 64 + lane]);
-                r.w[2 * g + 1] = ld_stream<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
-            }
-            r.c[g] = ld_stream<kNT>(&cbase[g * 64 + lane]);
-        } else {
-            if (kDict == kWBytes) {
-                if ((g & 1) == 0) r.wi[g >> 1] = 0u;
-            } else if (kDict == kWWords) {
-                r.wi[g] = 0u;
-            } else if (kDict == kWPlain) {
-                r.w[2 * g] = (WT)0;
-                r.w[2 * g + 1] = (WT)0;
-            }
-            r.c[g] = 0u;
-        }
-    }
-}
-
-template <typename WT, int kCh, int kCopies, int kDict>
-__device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32_t width, uint32_t s,
-                                           uint32_t lane, const WT *__restrict__ wbase,
-                                           const uint32_t *__restrict__ cbase, const TileDesc &td,
-                                           const double *theta_l, double *cnt_l, double *den_l,
-                                           const uint32_t *__restrict__ row_w_perm,
-                                           const uint32_t *__restrict__ ibase, const float *dict_l, uint32_t exp_mask, uint32_t cs)
-{
-    // weight of alignment j >= kCh of the lane's read (reload loops)
-    auto w_at = [&](uint32_t j) -> double {
-        if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
-        if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
-        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
-        return (double)wbase[j * 64 + lane];
-    };
-    const uint32_t rl = s * 64 + lane;
-    __builtin_amdgcn_sched_barrier(0);
-    // Land every operand of this slice here (the loads of the NEXT slice stay in flight):
-    // one counted s_waitcnt in front of the fold instead of a wait per alignment woven
-    // through the LDS traffic.  Measured: 0.272 -> 0.237 ms per pass at C3.
-    if (kDict == kWBytes) {
-#pragma unroll
-        for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(cur.wi[k]));
-    } else if (kDict == kWWords) {
-#pragma unroll
-        for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.wi[k]));
-    } else if (kDict == kWPlain) {
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(cur.w[k]));
-    }
-#pragma unroll
-    for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(cur.c[k]));
-    // the second element of the last pair of an odd-width slice belongs to the next row: it must
-    // carry no weight.  Done once here, so the passes below need no per-alignment select.
-    WT wz[kCh];
-#pragma unroll
-    for (int k = 0; k < kCh; ++k)
-        wz[k] = (kDict == kWPlain && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(cur, k, dict_l);
-    double x[kCh];
-    double denom = den_l[rl];
-#pragma unroll
-    for (int k = 0; k < kCh; ++k) {
-        const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
-        x[k] = lds_ld(theta_l, OEM_EXP(8u) ? lane * 8u : off) * (double)wz[k]; // em.rs:111
-        denom += x[k];
-    }
-    for (uint32_t j = kCh; j < width; ++j) { // reads with more than kCh local alignments
-        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
-        denom += lds_ld(theta_l, off) * w_at(j);
-    }
-    double scale = 1.0;
-    if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
-    const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
-    den_l[rl] = inv;
-
-    // The count window is kept in 1 << cs interleaved copies (entry c of copy p at
-    // ((c << cs) + p) * 8): lanes of different copies that add into the same
-    // transcript hit different addresses (and adjacent banks), which divides the
-    // same-address serialisation of the LDS atomics by up to the number of copies.
-    const uint32_t copy_off = (lane & ((1u << cs) - 1u)) * 8u;
-    // k = 0 is the read's anchor.  Inside a highly expressed transcript all 64 lanes
-    // share it, and 64 same-address LDS atomics would serialise: reduce across the
-    // wavefront and let one lane add.
-    {
-        const uint32_t off0 = code_off<kDict>(code_half(cur.c[0], 0));
-        const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
-        const double v0 = x[0] * inv;
-        if (__all(off0 == u)) {
-            const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u << cs), sum);
-        } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, (off0 << cs) + copy_off), v0);      // em.rs:128-129
-        }
-    }
-#pragma unroll
-    for (int k = 1; k < kCh; ++k) {
-        if ((uint32_t)k < width) { // uniform
-            const uint32_t off = code_off<kDict>(code_half(cur.c[k >> 1], k & 1));
-            const double v = x[k] * inv;
-            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
-        }
-    }
-    for (uint32_t j = kCh; j < width; ++j) {
-        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
-        const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
-    }
-}
-
-// A remote record (oem_layout_pack.hip): kPacked: one u32 = (transcript - problem base) | read << 22;
-// otherwise transcript u32 + read u16.  Its queue slot comes from the tile's slot table.
-template <bool kPacked, bool kNT>
-__device__ __forceinline__ void ld_remote(const uint32_t *__restrict__ r_a, const uint16_t *__restrict__ r_row, uint32_t o,
-                                          uint32_t tid_base, uint32_t &t, uint32_t &row)
-{
-    if (kPacked) {
-        const uint32_t pk = ld_stream<kNT>(&r_a[o]);
-        t = tid_base + (pk & ((1u << kPackRowShift) - 1u));
-        row = pk >> kPackRowShift;
-    } else {
-        t = ld_stream<kNT>(&r_a[o]);
-        row = ld_stream<kNT>(&r_row[o]);
-    }
-}
-
-// The FIRST slice of a wavefront is the widest of its four (a tile's reads are ordered by local-alignment
-// count and dealt to the wavefronts round-robin), and at 8 alignments per read on average it is wider than the
-// kCh = 8 a register set holds: its alignments 8..15 used to go through the reload loops of fold_slice -- two
-// synchronous loads per alignment in the middle of the fold, each wait also draining the prefetch of the next
-// slice.  In-kernel timestamps (scripts/tile_probe.py, profiles/r03_notes.md) put 7.8 us of a tile's 26 us
-// there.  Both register sets are idle until the local phase begins, so the first slice's alignments 8..15 are
-// loaded into the SECOND set with everything else at the top of the kernel (hidden behind the remote phases);
-// the fold runs over 16 register-resident alignments, hands the first set to the next slice's prefetch as
-// soon as its own scatter is done with it, and only reads with more than 16 local alignments reload.
-template <typename WT, int kCh, int kCopies, bool kNT, int kDict>
-__device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRegs<WT, kCh> &hi, uint32_t width, uint32_t s,
-                                           uint32_t lane, const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase,
-                                           const TileDesc &td, const double *theta_l, double *cnt_l, double *den_l,
-                                           const uint32_t *__restrict__ row_w_perm, bool prefetch_next,
-                                           const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c, uint32_t next_width,
-                                           const uint32_t *__restrict__ ibase, const uint32_t *__restrict__ next_i,
-                                           const float *dict_l, uint32_t exp_mask, uint32_t cs)
-{
-    auto w_at = [&](uint32_t j) -> double {
-        if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
-        if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
-        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
-        return (double)wbase[j * 64 + lane];
-    };
-    const uint32_t rl = s * 64 + lane;
-    __builtin_amdgcn_sched_barrier(0);
-    if (kDict == kWBytes) {
-#pragma unroll
-        for (int k = 0; k < kCh / 4; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
-    } else if (kDict == kWWords) {
-#pragma unroll
-        for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(lo.wi[k]), "v"(hi.wi[k]));
-    } else if (kDict == kWPlain) {
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) asm volatile("" ::"v"(lo.w[k]), "v"(hi.w[k]));
-    }
-#pragma unroll
-    for (int k = 0; k < kCh / 2; ++k) asm volatile("" ::"v"(lo.c[k]), "v"(hi.c[k]));
-    // (load_slice zero-fills beyond the width; the second element of the last pair of an odd width belongs to
-    // the next row and must carry no weight)
-    double x[kCh];
-    double denom = den_l[rl];
-#pragma unroll
-    for (int k = 0; k < kCh; ++k) {
-        const WT wk = (kDict == kWPlain && (k & 1) && (uint32_t)k >= width) ? (WT)0 : slice_w<kDict>(lo, k, dict_l);
-        const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
-        x[k] = lds_ld(theta_l, OEM_EXP(8u) ? lane * 8u : off) * (double)wk;      // em.rs:111
-        denom += x[k];
-    }
-    if (width > (uint32_t)kCh) { // wave-uniform
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) {
-            const WT wk = (kDict == kWPlain && (k & 1) && (uint32_t)(k + kCh) >= width) ? (WT)0 : slice_w<kDict>(hi, k, dict_l);
-            const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
-            denom += lds_ld(theta_l, off) * (double)wk;
-        }
-    }
-    for (uint32_t j = 2 * kCh; j < width; ++j) { // reads with more than 16 local alignments
-        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
-        denom += lds_ld(theta_l, off) * w_at(j);
-    }
-    double scale = 1.0;
-    if (row_w_perm) scale = rl < td.n_rows ? (double)row_w_perm[td.row_base + rl] : 0.0;
-    const double inv = denom > OEM_EM_DENOM_THRESH ? scale / denom : 0.0;  // em.rs:115
-    den_l[rl] = inv;
-    const uint32_t copy_off = (lane & ((1u << cs) - 1u)) * 8u;
-    {
-        const uint32_t off0 = code_off<kDict>(code_half(lo.c[0], 0));
-        const uint32_t u = __builtin_amdgcn_readfirstlane(off0);
-        const double v0 = x[0] * inv;
-        if (__all(off0 == u)) {
-            const double sum = wave_sum_f64(v0);
-            if (lane == 0 && sum != 0.0) lds_add_f64(lds_at(cnt_l, u << cs), sum);
-        } else if (v0 != 0.0) {
-            lds_add_f64(lds_at(cnt_l, (off0 << cs) + copy_off), v0);      // em.rs:128-129
-        }
-    }
-#pragma unroll
-    for (int k = 1; k < kCh; ++k) {
-        if ((uint32_t)k < width) { // uniform
-            const uint32_t off = code_off<kDict>(code_half(lo.c[k >> 1], k & 1));
-            const double v = x[k] * inv;
-            if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
-        }
-    }
-    // the first register set is done: the next slice's loads go out now, under the rest of this fold
-    if (prefetch_next) load_slice<WT, kCh, kNT, kDict>(lo, next_w, next_c, lane, next_width, next_i);
-    if (width > (uint32_t)kCh) {
-#pragma unroll
-        for (int k = 0; k < kCh; ++k) {
-            if ((uint32_t)(k + kCh) < width) { // uniform
-                const uint32_t off = code_off<kDict>(code_half(hi.c[k >> 1], k & 1));
-                const double v = lds_ld(theta_l, off) * (double)slice_w<kDict>(hi, k, dict_l) * inv;
-                if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
-            }
-        }
-    }
-    for (uint32_t j = 2 * kCh; j < width; ++j) {
-        const uint32_t cc = cbase[(j >> 1) * 64 + lane];
-        const uint32_t off = code_off<kDict>(code_half(cc, j & 1));
-        const double v = lds_ld(theta_l, off) * w_at(j) * inv;
-        if (v != 0.0 && !OEM_EXP(4u)) lds_add_f64(lds_at(cnt_l, (off << cs) + copy_off), v);
-    }
-}
 
 template <typename WT, int kCh, int kRem, int kTileThreads, int kMinWaves, int kCopies, bool kNT, uint32_t kWinT, bool kPacked, int kDict, int kSetsT>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
@@ -815,9 +447,12 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     } while (0)
     // (a store whose codes carry the fused index has no other way to be read; the knob -- testing build, A/B --
     // switches only the byte-stream coding off)
+    const bool pipelined = tile_pipeline_applies(s, problems); // oem_tile_pipe.hip: measured, not shipped (test-only library)
+    if (pipelined) OEM_TRY(launch_tile_pipeline(s, theta, cnt, state, row_w_perm, nt));
     const bool coded = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
     const bool bytes = coded && !t.dict_words, words = coded && t.dict_words;
-    if (f64w) {
+    if (pipelined) {
+    } else if (f64w) {
         if (nt) OEM_TILE(double, true, t.w64, t.r_w64, kWPlain);
         else OEM_TILE(double, false, t.w64, t.r_w64, kWPlain);
     } else if (words) {
@@ -865,6 +500,7 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 } // namespace oem
 
 #ifdef OEM_TESTING
+namespace oem { int pipe_probe_set(unsigned long long *d); } // oem_tile_pipe.hip
 // Test hook: one probed E/M pass (after an unprobed one); out = n_tiles x 16 wall-clock stamps (100 MHz).
 extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint64_t n_out)
 {
@@ -884,10 +520,12 @@ extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint6
     OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr));   // warm
     OEM_HIP(hipStreamSynchronize(s->stream));
     OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &d, sizeof(d)));
+    OEM_TRY(pipe_probe_set(d)); // (whichever of the two tile kernels the store takes)
     int rc = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr);
     hipStreamSynchronize(s->stream);
     unsigned long long *null = nullptr;
     hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &null, sizeof(null));
+    pipe_probe_set(nullptr);
     if (rc == OEM_OK && hipMemcpy(out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(OEM_ERR_HIP, "oem_debug_tile_probe: read-back failed");
     hipFree(d);

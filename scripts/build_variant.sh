@@ -4,9 +4,9 @@
 set -e
 dir=$1; defs=$2
 cd "$(dirname "$0")/.."
-rm -f oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
+rm -f oarfish_amd/csrc/_obj/oem_tile_pipe*.o oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
 OEM_EXTRA_DEFS="$defs" python -m oarfish_amd.build > /dev/null 2>&1
 mkdir -p "$dir"; cp oarfish_amd/liboarfish_em.so oarfish_amd/liboarfish_em_testing.so "$dir"/
-rm -f oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
+rm -f oarfish_amd/csrc/_obj/oem_tile_pipe*.o oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o
 python -m oarfish_amd.build > /dev/null 2>&1
 echo "built $dir with $defs"

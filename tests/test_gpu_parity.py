@@ -862,6 +862,38 @@ def test_full_size_c3_to_convergence_matches_oracle_under_both_gates():
         assert abs(cnt.sum() - st.n_reads) < 1e-7 * st.n_reads
 
 
+@pytest.mark.timeout(1500)
+def test_full_size_c3_device_drawn_replicate_to_its_own_convergence_matches_oracle():
+    """BASELINE configs[2]'s "+ bootstraps" leg as the bench runs it: replicates whose resamples the DEVICE draws
+    (Philox, `get_sample_inds` in multiplicity form, bootstrap.rs:7-16), each run through the batched path to ITS OWN
+    convergence with the reference's defaults (em.rs:273-290: do_em over the resampled reads, gate 50).  Replicate 0
+    against the serial oracle on the same multiplicities -- every transcript, iteration count +- 1 (~900 passes of
+    ~0.2 s) -- beside two more slots that stop at their own iterations: checked against the one-replicate-per-pass
+    path (k_em_tile with per-read multiplicities), which shares no kernel with the batched one."""
+    st = synth.make_config("c3")
+    T = st.n_txps
+    seed = 20260929
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as d:
+        w0 = d.bootstrap_weights(seed, 0)                   # what the batched path draws for replicate 0
+        assert int(w0.sum()) == st.n_reads and int((w0 == 0).sum()) > 0.3 * st.n_reads
+        bout, binfo = d.bootstrap(3, seed=seed, max_iter=1000, conv_thresh=1e-3)          # nothing injected
+        d.set_option(_lib.OEM_OPT_BATCH_BOOTSTRAP, 0)
+        sout, sinfo = d.bootstrap(2, seed=seed, max_iter=1000, conv_thresh=1e-3, first_replica=1)
+    for b in range(3):
+        assert binfo[b].niter > 51 and binfo[b].n_passes == binfo[b].niter + (2 if binfo[b].converged else 1), binfo[b]
+        assert abs(bout[b].sum() - st.n_reads) < 1e-7 * st.n_reads      # a resample keeps the read count
+    assert len({i.niter for i in binfo}) > 1, [i.niter for i in binfo]  # the slots stopped at iterations of their own
+    for k in (1, 2):   # batched slot vs the same replicate alone on the point-estimate kernels
+        assert binfo[k].niter == sinfo[k - 1].niter, (k, binfo[k], sinfo[k - 1])
+        assert_counts_close(bout[k], sout[k - 1], st.n_reads, T, 1e-8, f"replicate {k}: batched vs one per pass")
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    want, wi = c_oracle.do_em(o, row_w=w0, max_iter=1000, conv_thresh=1e-3, min_iter_gate=50)
+    assert abs(binfo[0].niter - wi.niter) <= 1, (binfo[0], wi)
+    assert binfo[0].converged == wi.converged
+    assert_counts_close(bout[0], want, st.n_reads, T, RTOL if binfo[0].niter != wi.niter else 1e-8,
+                        "c3 device-drawn replicate 0 to its own convergence")
+
+
 @pytest.mark.timeout(900)
 def test_full_size_c3_coverage_store_matches_oracle():
     """The C3-sized store WITH the coverage column (--model-coverage, the authors' recommended mode: f64 weights
@@ -946,6 +978,50 @@ def test_c5_slice_of_one_gpu_properties():
     for c in range(8):
         assert infos8[c].niter == infos[c].niter
         assert_counts_close(out8[c], out[c], per_cell, T, 1e-9, f"cell {c}: batch of 8 vs batch of 625")
+
+
+@pytest.mark.timeout(1800)
+def test_c5_whole_5000_cells_in_one_call():
+    """BASELINE configs[4] WHOLE on one GPU: 5 000 cells x 50 k reads (250 M reads, 2 G alignments, 21 GB of host
+    arrays) in ONE oem_em_run_cells call (eight groups of ~660 cells on two host threads, single_cell.rs:139-160 per
+    cell).  The cells are 625 generated ones x 8 transcript-id rotations (synth.replicate_cells: a relabelling is an
+    exact symmetry of the EM, and generating 5 k cells in Python would take the driver's tier ten minutes), so besides
+    per-cell mass conservation, unique <= count <= total and "a batch of 8 = the same cells in the batch of 5 000",
+    every rotated copy must reproduce its base cell's counts under the rotation -- through other ids, tiles and
+    windows, in another group of the call."""
+    n_cells, n_base, per_cell, T = 5_000, 625, 50_000, 60_000
+    base = synth.make_cells(n_base, per_cell, T, seed=37, threads=min(32, os.cpu_count() or 4))
+    cell_off, row_ptr, tid, p = synth.replicate_cells(base, T, n_cells)
+    assert len(cell_off) == n_cells + 1 and int(cell_off[-1]) == n_cells * per_cell
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=1000, convergence_thresh=1e-3)
+    assert out.shape == (n_cells, T)
+    assert np.abs(out.sum(axis=1) - per_cell).max() < 1e-6 * per_cell         # mass conservation, every cell
+    passes = np.array([i.n_passes for i in infos])
+    assert passes.min() >= 53 and passes.max() <= 1001 and len(set(passes.tolist())) > 20
+    for c in (0, 2_499, 4_999):   # unique <= count <= total, from the cell's own alignments
+        r0, r1 = int(cell_off[c]), int(cell_off[c + 1])
+        a0, a1 = int(row_ptr[r0]), int(row_ptr[r1])
+        lens = (row_ptr[r0 + 1:r1 + 1] - row_ptr[r0:r1]).astype(np.int64)
+        tot = np.bincount(tid[a0:a1], minlength=T)
+        uniq = np.bincount(tid[a0:a1][np.repeat(lens == 1, lens)], minlength=T)
+        assert np.all(out[c] >= uniq - 1e-6) and np.all(out[c] <= tot + 1e-6), c
+    # a rotated copy = its base cell under the rotation (copies of one cell sit in different groups of the call)
+    worst = 0
+    for c in list(range(0, n_base, 7)) + [n_base - 1]:
+        for r in range(1, n_cells // n_base):
+            k = r * n_base + c
+            back = np.roll(out[k], -synth.cell_shift(r, T))
+            dn = abs(infos[k].niter - infos[c].niter)
+            worst = max(worst, dn)
+            assert dn <= 1, (c, r, infos[k], infos[c])
+            assert_counts_close(back, out[c], per_cell, T, RTOL if dn else 1e-8, f"cell {c}, rotation {r}")
+    # the first 8 cells as a batch of their own: the same answers (a cell's run does not depend on its batch)
+    r8 = int(cell_off[8]); a8 = int(row_ptr[r8])
+    out8, infos8 = oarfish_amd.em_cells(cell_off[:9], row_ptr[:r8 + 1], tid[:a8], p[:a8], None, T, max_iter=1000,
+                                        convergence_thresh=1e-3)
+    for c in range(8):
+        assert infos8[c].niter == infos[c].niter
+        assert_counts_close(out8[c], out[c], per_cell, T, 1e-9, f"cell {c}: batch of 8 vs batch of 5000")
 
 
 @pytest.mark.parametrize("name", ["c2"])
