@@ -51,6 +51,8 @@ def parse(argv=None):
     ap.add_argument("--bootstraps", type=int, default=100,
                     help="bootstrap replicates to time per GPU (0 = skip; default 100 = BASELINE configs[2])")
     ap.add_argument("--no-batch-bootstrap", action="store_true", help="one replicate per pass instead of the batched chains")
+    ap.add_argument("--cells-full", type=int, default=None,
+                    help="cells of the whole-configs[4] leg on one GPU (default 5000 for c3 at N=1; 0 = skip)")
     ap.add_argument("--cells", type=int, default=None,
                     help="cells of the per-cell leg per GPU (0 = skip; default 625 for c3 = BASELINE configs[4]'s 5 k cells "
                          "over 8 GPUs, 16 otherwise)")
@@ -239,6 +241,9 @@ def hbm_traffic(workload):
     return None, None, None
 
 
+AFFINITY_AT_START = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+
 def bind_to_gpu_numa_node(torch, device):
     """Run this process on the CPUs next to its GPU, as `numactl --cpunodebind` in a launcher would: the caller-side
     arrays are pageable host memory, first touched by the thread that fills them, and the boundary copies them over
@@ -323,7 +328,13 @@ def main():
     t_up = time.perf_counter() - t_up
     comm = None
     exchange = None
+    shard_compute_us = None
     if dist_mode:
+        # What this rank's shard costs by itself: whole EM iterations of the un-attached shard store (tile kernel, fold,
+        # rel-diff / swap / clear, no exchange), HIP-event-timed -- beside the exchange's own time and the sharded
+        # iteration below, so that a scaling curve says which of the two did not scale (config.exchange).
+        store.time_em_iters(20)
+        shard_compute_us = store.time_em_iters(100) / 100 * 1e3
         # RCCL plus the one-shot peer-to-peer exchange for the 1.6 MB count vector (oem_p2p.hip); world 1 under
         # --force-dist: a real one-rank RCCL communicator and a one-rank exchange buffer
         comm = odist.create_comm(rank, world, local_rank, backend="p2p" if args.same_device else "both",
@@ -331,6 +342,21 @@ def main():
         store.attach_comm(comm.handle, cfg["n_reads"], r0)
         # (--same-device: no RCCL -- it refuses two ranks per device -- and a gloo group for the agreement)
         exchange = pick_exchange(store, comm, dist, torch, have_rccl=not args.same_device, cpu_group=args.same_device)
+        # the three numbers of one rank's iteration side by side, per candidate: the shard's compute alone, the
+        # exchange alone (back-to-back all-reduces of the count vector), the sharded iteration as timed
+        sc = torch.tensor([shard_compute_us], dtype=torch.float64, device="cpu" if args.same_device else "cuda")
+        per_rank = [torch.zeros_like(sc) for _ in range(world)]
+        dist.all_gather(per_rank, sc)
+        exchange["shard_compute_us"] = max(float(t.item()) for t in per_rank)
+        exchange["shard_compute_us_per_rank"] = [round(float(t.item()), 2) for t in per_rank]
+        for rec in exchange["candidates"].values():
+            if rec.get("ok"):
+                rec["exchange_us"] = rec["allreduce_us"]
+                rec["shard_compute_us"] = exchange["shard_compute_us"]
+                rec["iteration_minus_compute_us"] = rec["iteration_us"] - exchange["shard_compute_us"]
+        exchange["ranks"] = comm.info(_lib.OEM_COMM_INFO_RANKS)
+        exchange["rccl_ranks_seen"] = comm.info(_lib.OEM_COMM_INFO_RCCL_RANKS)   # ncclCommCount; 0: no RCCL in this run
+        exchange["p2p_connected_this_rank"] = bool(comm.info(_lib.OEM_COMM_INFO_P2P_CONNECTED))
 
     def sync():
         torch.cuda.synchronize()
@@ -392,9 +418,10 @@ def main():
                     pit = o.time_em_iters(args.steps) / args.steps
                     _h, ab = o.bytes()
                     nd = o.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
+                    nrem = o.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS)
                 roofline["frac_" + label] = ab / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roofline[label] = dict(kernel_avg_ms=pk, device_ms_per_step=pit, algorithmic_bytes_per_launch=ab,
-                                       weight_coding=coding_of(nd), weight_dict_entries=nd)
+                                       weight_coding=coding_of(nd), weight_dict_entries=nd, remote_alignments=nrem)
             except Exception as e:  # pragma: no cover
                 roofline[label] = dict(error=repr(e))
         if n_dict:
@@ -409,6 +436,15 @@ def main():
             ug = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=threads, gaps="uniform")
             timed("uniform_gaps", ug.row_ptr, ug.tid, ug.as_prob, None)
             del ug
+            # What the engine does when a read's far alignments RECUR (multi-mapping reads hit paralogs, not random
+            # transcripts): the BASELINE generator's 20 % uniformly random far hits are the worst case of the remote
+            # path (a quarter of the pass).  `paralog`: far hits inside families of three genes scattered over the
+            # annotation; `paralog_adjacent`: the same families numbered next to each other -- the annotation a
+            # co-mapping renumbering at store creation would produce (not built: this prices it).
+            for far in ("paralog", "paralog_adjacent"):
+                pf = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=threads, far=far)
+                timed(far, pf.row_ptr, pf.tid, pf.as_prob, None)
+                del pf
 
     # EM to convergence with the reference's defaults (max_iter 1000, thresh 1e-3), both gates
     sync()
@@ -433,6 +469,13 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU legs run on every CPU the cgroup grants, not on the GPU's NUMA node alone (the binding above would
+        # hand the reference's side fewer cores on a multi-socket box and flatter the ratio)
+        if AFFINITY_AT_START:
+            try:
+                os.sched_setaffinity(0, AFFINITY_AT_START)
+            except OSError:
+                pass
         cpu = cpu_baseline(row_ptr, tid, p, cfg["n_txps"], args.cpu_seconds)
         if boots and boots.get("value"):
             boots["cpu_baseline"] = cpu_boot_baseline(row_ptr, tid, p, cfg["n_txps"], args.cpu_seconds,
@@ -606,6 +649,23 @@ def bootstrap_leg(args, cfg, full, store, dist_mode, rank, world, local_rank, sy
                 chains=1 if args.no_batch_bootstrap else 2, roofline=roof)
 
 
+def cells_traffic(n_cells, per_cell, T):
+    """HBM bytes of the whole batched loop of the 625-cell slice from the tracked PMC passes
+    (scripts/collect_cells_traffic.sh -> profiles/r0N_c5_cells625_hbm_traffic.json), when the leg is that slice."""
+    if (n_cells, per_cell, T) != (625, 50_000, 60_000):
+        return None, None
+    for tag in ("r05", "r04"):
+        q = os.path.join(ROOT, "profiles", f"{tag}_c5_cells625_hbm_traffic.json")
+        if os.path.exists(q):
+            try:
+                j = json.load(open(q))
+                v = j.get("loop_total_bytes")
+                return (int(v) if v else None), os.path.relpath(q, ROOT)
+            except Exception:
+                return None, None
+    return None, None
+
+
 def cells_leg(args, n_cells, rank, world, local_rank, sync, max_over_ranks):
     """BASELINE configs[4]: per-cell EM, gate 50, init None, every cell to its own convergence.
     n_cells PER GPU (weak scaling: 5 k cells over 8 GPUs = 625 each); end to end from host buffers
@@ -644,7 +704,9 @@ def cells_leg(args, n_cells, rank, world, local_rank, sync, max_over_ranks):
             reads_c = co[1:] - co[:-1]
             nbytes = int(np.sum(np.asarray(passes, dtype=np.int64) * (nnz_c * 8 + (reads_c + 1) * 4 + 2 * T * 8)))
             ach = nbytes / (loop_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+            ctraffic, csrc = cells_traffic(n_cells, per_cell, T)
+            roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=ctraffic,
+                        traffic_source=csrc,
                         kernel="k_em_tile + k_multi_fold_reldiff + per-cell state kernels (all passes of the batched loop)",
                         loop_ms=loop_ms, batched_passes=batched, kernel_avg_ms=loop_ms / max(batched, 1),
                         algorithmic_bytes_total=nbytes,
@@ -660,7 +722,39 @@ def cells_leg(args, n_cells, rank, world, local_rank, sync, max_over_ranks):
     elif err:
         return dict(value=None, error=err)
     tc = max_over_ranks(tc)
-    return dict(value=total / tc, unit="cells/s", n_cells=total, reads_per_cell=per_cell, n_txps=T,
+    # BASELINE configs[4] WHOLE on this one GPU (5 k cells x 50 k reads, 2 G alignments) in ONE oem_em_run_cells call:
+    # the generated cells x transcript-id rotations (synth.replicate_cells -- a relabelling is an exact symmetry of the
+    # EM, and 5 k cells take minutes to generate in Python), end to end from host buffers like the slice above
+    full_leg = None
+    n_full = args.cells_full if args.cells_full is not None else (5000 if args.workload == "c3" and n_cells >= 625 else 0)
+    if world == 1 and n_full > n_cells and not err:
+        try:
+            tr = time.perf_counter()
+            fco, frp, ftid, fp = synth.replicate_cells((cell_off, row_ptr, tid, p), T, n_full)
+            tr = time.perf_counter() - tr
+            t0 = time.perf_counter()
+            _a, _b, fout, finfos = odist.em_cells_sharded(fco, frp, ftid, fp, None, T, 0, 1, device=local_rank)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - t0
+            fp_ = np.asarray([i.n_passes for i in finfos])
+            # a rotated copy must reproduce its base cell under the rotation (the first copy of every 50th cell)
+            worst = 0.0
+            for c in range(0, n_cells, 50):
+                k = n_cells + c
+                if k < n_full:
+                    back = np.roll(fout[k], -synth.cell_shift(1, T))
+                    worst = max(worst, float(np.max(np.abs(back - fout[c]) / np.maximum(np.abs(fout[c]), 1e-5 * per_cell / T))))
+            full_leg = dict(value=n_full / tf, unit="cells/s", n_cells=n_full, seconds=tf, alignments=int(len(ftid)),
+                            host_gb=round((fco.nbytes + frp.nbytes + ftid.nbytes + fp.nbytes) / 1e9, 1),
+                            mean_passes=float(fp_.mean()), max_passes=int(fp_.max()),
+                            worst_mass_error=float(np.abs(fout.sum(axis=1) - per_cell).max()),
+                            worst_rel_diff_rotated_copy_vs_base=worst, replicate_s=round(tr, 2),
+                            data=f"{n_cells} generated cells x {-(-n_full // n_cells)} transcript-id rotations (synth.replicate_cells)",
+                            mode="one oem_em_run_cells call: groups of ~660 cells on two host threads")
+            del fco, frp, ftid, fp, fout
+        except Exception as e:  # pragma: no cover
+            full_leg = dict(value=None, error=repr(e))
+    return dict(value=total / tc, unit="cells/s", n_cells=total, reads_per_cell=per_cell, n_txps=T, cells_full=full_leg,
                 seconds=tc, mean_passes=float(np.mean(passes)), max_passes=int(np.max(passes)),
                 worst_mass_error=mass, gen_s=round(tg, 2), roofline=roof,
                 mode=f"{n_cells} cells per GPU, batched on the device, no collective")

@@ -77,10 +77,11 @@ typedef struct {
     uint32_t layout_build; /* 0 = build the tiled layout on the device (the host builder takes the stores the
                               device builder declines); 1 = always the host builder (oem_layout.cpp, the
                               specification the device builder is tested against) */
-    uint32_t weight_coding; /* 0 = a store with at most 256 distinct f32 weights (as_prob is exp of an integer score
+    uint32_t weight_coding; /* 0 = a store with at most 1024 distinct f32 weights (as_prob is exp of an integer score
                               gap over a constant: tens to hundreds of values) keeps its weights as indices into a
                               table of them -- in the spare bits of the window codes up to 128 values, a byte each up
-                              to 256; lossless, oem_layout_dict.hip; 1 = always the f32 stream (was reserved[0]) */
+                              to 256, 16 bits each up to 1024 (wide-window stores: up to 256, a byte each); lossless,
+                              oem_layout_dict.hip; 1 = always the f32 stream (was reserved[0]) */
     uint32_t reserved[3];
 } oem_store_opts;
 
@@ -342,10 +343,20 @@ int oem_comm_p2p_connect(oem_comm *comm, const void *all_handles /* n_ranks x OE
  * OEM_COMM_OPT_P2P_SELF_CHECK (set BEFORE oem_comm_p2p_connect): 1 = connect ends with a checked exchange in both
  * shapes against a closed-form sum -- also the ranks' rendezvous, with a long wait (120 s), so a peer that is still
  * building its store does not time the EM loop's first exchange out.  Needs every rank inside connect at the same
- * time (ranks = processes); a failure leaves the peer-to-peer backend disconnected (RCCL, if any, carries on). */
+ * time (ranks = processes); a failure leaves the peer-to-peer backend disconnected (RCCL, if any, carries on).
+ * Value 2, AFTER oem_comm_p2p_connect: run that checked exchange now -- for hosts that first make sure every rank has
+ * mapped its peers (oarfish_amd.dist gathers one byte per rank), so that a rank whose connect failed does not leave the
+ * others waiting in a kernel for the rendezvous bound (the longer of OEM_COMM_OPT_P2P_TIMEOUT_MS and 120 s). */
 typedef enum { OEM_COMM_OPT_P2P_MAX_BYTES = 1, OEM_COMM_OPT_P2P_SHAPE = 2, OEM_COMM_OPT_P2P_TIMEOUT_MS = 3,
                OEM_COMM_OPT_P2P_SELF_CHECK = 4 } oem_comm_option;
 int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t value);
+
+/* What a communicator is made of, for the host's records (bench.py's config.exchange): OEM_COMM_INFO_RANKS = n_ranks
+ * as created; OEM_COMM_INFO_RCCL_RANKS = the number of ranks RCCL itself reports for its communicator
+ * (ncclCommCount; 0 without RCCL) -- the first multi-GPU run says from the library's own mouth how many ranks the
+ * collective spanned; OEM_COMM_INFO_P2P_CONNECTED = 1 when the peer-to-peer exchange is mapped on this rank. */
+typedef enum { OEM_COMM_INFO_RANKS = 1, OEM_COMM_INFO_RCCL_RANKS = 2, OEM_COMM_INFO_P2P_CONNECTED = 3 } oem_comm_info_key;
+int oem_comm_info(const oem_comm *comm, uint32_t key, uint64_t *out);
 
 /* Declare `store` to be rank-local row shard of a store with
  * `global_n_reads` reads in total (needed for the uniform init, em.rs:154,165).

@@ -27,6 +27,9 @@ OEM_COMM_OPT_P2P_MAX_BYTES = 1
 OEM_COMM_OPT_P2P_SHAPE = 2
 OEM_COMM_OPT_P2P_TIMEOUT_MS = 3
 OEM_COMM_OPT_P2P_SELF_CHECK = 4
+OEM_COMM_INFO_RANKS = 1
+OEM_COMM_INFO_RCCL_RANKS = 2
+OEM_COMM_INFO_P2P_CONNECTED = 3
 OEM_INFO_WEIGHT_DICT_ENTRIES = 1
 OEM_INFO_TILES = 2
 OEM_INFO_REMOTE_ALIGNMENTS = 3
@@ -43,7 +46,7 @@ ABI_SYMBOLS = [
     "oem_bootstrap_weights", "oem_bootstrap",
     "oem_em_run_cells",
     "oem_comm_unique_id", "oem_comm_create", "oem_comm_destroy", "oem_comm_p2p_export", "oem_comm_p2p_connect",
-    "oem_comm_set_option", "oem_store_attach_comm",
+    "oem_comm_set_option", "oem_comm_info", "oem_store_attach_comm",
     "oem_time_m_step", "oem_time_em_iters", "oem_time_bootstrap_passes", "oem_time_allreduce",
     "oem_cells_last_timing",
 ]
@@ -146,6 +149,7 @@ def _load(path: str) -> C.CDLL:
     L.oem_comm_p2p_export.argtypes = [vp, u64, vp]
     L.oem_comm_p2p_connect.argtypes = [vp, vp]
     L.oem_comm_set_option.argtypes = [vp, u32, u64]
+    L.oem_comm_info.argtypes = [vp, u32, C.POINTER(u64)]
     L.oem_time_allreduce.argtypes = [vp, u32, C.POINTER(C.c_float)]
     L.oem_store_attach_comm.argtypes = [vp, vp, u64, u64]
     L.oem_time_m_step.argtypes = [vp, u32, C.POINTER(C.c_float)]

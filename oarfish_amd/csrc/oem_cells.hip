@@ -353,21 +353,21 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
     if (n_workers > kMaxWorkers) n_workers = kMaxWorkers;
     if ((size_t)n_workers > groups.size()) n_workers = (int)groups.size();
     if (n_workers < 1) n_workers = 1;
-    int rcs[kMaxWorkers] = {OEM_OK, OEM_OK, OEM_OK, OEM_OK};
+    int rcs[kMaxWorkers] = {OEM_OK, OEM_OK, OEM_OK, OEM_OK}; // each worker's own; read by the others only after the join
+    std::atomic<bool> failed{false};                         // ... and this is what they stop on
     std::string errs[kMaxWorkers];
     auto work = [&](int wk) {
         t_timing = &timing;
         if (wk != 0 && hipSetDevice(device) != hipSuccess) {
             rcs[wk] = OEM_ERR_HIP;
             errs[wk] = "hipSetDevice failed in a per-cell worker";
+            failed.store(true);
             return;
         }
         try {
             for (;;) {
                 const size_t g = next.fetch_add(1);
-                bool failed = false;
-                for (int k = 0; k < kMaxWorkers; ++k) failed = failed || rcs[k] != OEM_OK;
-                if (g >= groups.size() || failed) break;
+                if (g >= groups.size() || failed.load()) break;
                 rcs[wk] = run_cells_group(cell_row_off, groups[g].first, groups[g].second, row_ptr, tid, as_prob, cov_prob,
                                           n_txps, device, max_iter, conv_thresh, out, infos);
                 if (rcs[wk] != OEM_OK) break;
@@ -377,6 +377,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         } catch (...) {
             rcs[wk] = fail(OEM_ERR_STATE, "per-cell worker: unknown C++ exception");
         }
+        if (rcs[wk] != OEM_OK) failed.store(true);
         if (rcs[wk] != OEM_OK && errs[wk].empty()) errs[wk] = last_error_text(); // (the message is thread-local)
         t_timing = nullptr;
     };

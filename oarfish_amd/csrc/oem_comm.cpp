@@ -33,6 +33,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -62,6 +63,7 @@ int load_rccl()
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount"); // (optional: oem_comm_info only)
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce)
@@ -125,6 +127,7 @@ int p2p_check(P2P *p, hipStream_t st);
 void p2p_set_shape(P2P *p, int shape);
 int p2p_set_timeout_ms(P2P *p, uint64_t ms);
 void p2p_set_self_check(P2P *p, bool on);
+int p2p_checked_first_exchange(P2P *p);
 bool p2p_fine_grained(const P2P *p);
 
 // Vectors up to this size take the peer-to-peer exchange when it is connected (latency-bound: every
@@ -356,12 +359,39 @@ extern "C" int oem_comm_set_option(oem_comm *comm, uint32_t option, uint64_t val
         c->p2p_timeout_ms = value;
         return p2p_set_timeout_ms(c->p2p, value);
     case OEM_COMM_OPT_P2P_SELF_CHECK:
+        if (value == 2) { // run the checked first exchange NOW (after connect, once every rank is known to be mapped)
+            if (!c->p2p) return fail(OEM_ERR_STATE, "oem_comm_set_option: no peer-to-peer exchange to check");
+            return p2p_checked_first_exchange(c->p2p);
+        }
+        if (value > 2) return fail(OEM_ERR_ARG, "oem_comm_set_option: self check is 0, 1 (at the end of connect) or 2 (now)");
         c->p2p_self_check = value != 0;
         p2p_set_self_check(c->p2p, c->p2p_self_check);
         return OEM_OK;
     default: return fail(OEM_ERR_ARG, "oem_comm_set_option: unknown option %u", option);
     }
     OEM_API_END("oem_comm_set_option")
+}
+
+extern "C" int oem_comm_info(const oem_comm *comm, uint32_t key, uint64_t *out)
+{
+    OEM_API_BEGIN
+    const Comm *c = reinterpret_cast<const Comm *>(comm);
+    if (!c || !out) return fail(OEM_ERR_ARG, "oem_comm_info: NULL argument");
+    switch (key) {
+    case OEM_COMM_INFO_RANKS: *out = (uint64_t)c->n_ranks; return OEM_OK;
+    case OEM_COMM_INFO_RCCL_RANKS: {
+        int n = 0;
+        if (c->comm && g_api.CommCount) {
+            const ncclResult_t r = g_api.CommCount(c->comm, &n);
+            if (r != 0) return fail(OEM_ERR_RCCL, "ncclCommCount: %s", nccl_err(r));
+        }
+        *out = (uint64_t)n;
+        return OEM_OK;
+    }
+    case OEM_COMM_INFO_P2P_CONNECTED: *out = c->p2p && p2p_ready(c->p2p) ? 1u : 0u; return OEM_OK;
+    default: return fail(OEM_ERR_ARG, "oem_comm_info: unknown key %u", key);
+    }
+    OEM_API_END("oem_comm_info")
 }
 
 extern "C" void oem_comm_destroy(oem_comm *comm)

@@ -406,6 +406,7 @@ static uint64_t process_nonce()
 }
 
 int p2p_self_check(P2P *p);
+int p2p_checked_first_exchange(P2P *p);
 int p2p_set_timeout_ms(P2P *p, uint64_t ms);
 int p2p_allreduce(P2P *p, const double *send, double *recv, size_t count, hipStream_t st, const EmState *state);
 int p2p_check(P2P *p, hipStream_t st);
@@ -533,18 +534,33 @@ int p2p_connect(P2P *p, const void *all_blobs)
             h.peer[r] = static_cast<P2PShared *>(m);
         }
     }
-    h.timeout_ticks = (long long)(p->self_check ? kP2PSelfCheckTimeoutMs : p->timeout_ms) * kP2PTicksPerMs;
+    h.timeout_ticks = (long long)p->timeout_ms * kP2PTicksPerMs;
     OEM_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     p->connected = true;
-    if (p->self_check) {
-        const int rc = p2p_self_check(p);
-        if (rc != OEM_OK) {
-            p->connected = false; // the communicator falls back to RCCL (or reports that it has no backend)
-            return rc;
-        }
-        OEM_TRY(p2p_set_timeout_ms(p, p->timeout_ms));
-    }
+    if (p->self_check) return p2p_checked_first_exchange(p);
     return OEM_OK;
+}
+
+// The checked first exchange with the rendezvous' long wait: the longer of the caller's bound (OEM_COMM_OPT_P2P_TIMEOUT_MS)
+// and kP2PSelfCheckTimeoutMs.  Run at the end of connect (OEM_COMM_OPT_P2P_SELF_CHECK = 1 set before it), or on its
+// own once the host knows that EVERY rank has mapped its peers (= 2 after connect: a rank whose hipIpcOpenMemHandle
+// failed no longer leaves the others spinning in a kernel for the whole rendezvous bound).  A failure leaves the
+// exchange disconnected and its error latch cleared.
+int p2p_checked_first_exchange(P2P *p)
+{
+    if (!p2p_ready(p)) return fail(OEM_ERR_STATE, "peer-to-peer self check: the exchange is not connected");
+    OEM_HIP(hipSetDevice(p->device));
+    const uint64_t bound = p->timeout_ms > kP2PSelfCheckTimeoutMs ? p->timeout_ms : kP2PSelfCheckTimeoutMs;
+    const long long ticks = (long long)bound * kP2PTicksPerMs;
+    OEM_HIP(hipMemcpy(&p->ctl->timeout_ticks, &ticks, sizeof(ticks), hipMemcpyHostToDevice));
+    const int rc = p2p_self_check(p);
+    if (rc != OEM_OK) {
+        p->connected = false; // the communicator falls back to RCCL (or reports that it has no backend)
+        const uint32_t zero = 0;
+        (void)hipMemcpy(&p->ctl->error, &zero, sizeof(zero), hipMemcpyHostToDevice);
+        return rc;
+    }
+    return p2p_set_timeout_ms(p, p->timeout_ms);
 }
 
 int p2p_set_timeout_ms(P2P *p, uint64_t ms)

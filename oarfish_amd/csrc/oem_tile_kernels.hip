@@ -378,11 +378,12 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 
 } // namespace
 
-// Register blocking of k_em_tile (profiles/r01_notes.md has the variants that were measured and
-// dropped): 256 threads, 4 slices per wavefront with one slice prefetched ahead, 8 local and 6
-// remote alignments per thread in registers; 4 interleaved count-window copies for the narrow
-// window cap, one for the wide cap of sparse stores (40 KiB LDS; same-address atomics are rare
-// when few reads share a transcript).
+// Register blocking of k_em_tile (profiles/r01_notes.md .. r04_notes.md have the variants that were measured and
+// dropped): 256 threads, 4 slices per wavefront, as many of them register-resident before the fold as the weight
+// coding's register sets allow (tile_sets: all of them for the coded weights and the f32 stream, three sets for f64
+// weights, two for the wide window), 8 local and 6 remote alignments per thread in registers; 4 to 8 interleaved
+// count-window copies for the narrow window cap (by the tile's window), one for the wide cap of sparse stores
+// (40 KiB LDS; same-address atomics are rare when few reads share a transcript).
 template <typename WT, bool kNT, bool kPacked, int kDict>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
                         const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
@@ -425,12 +426,15 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
 #ifdef OEM_TESTING
-    {
-        static unsigned int current = 0;
+    { // (per-cell groups launch from two host threads, and a process may drive several devices)
+        static std::mutex mu;
+        static unsigned int current[64] = {0};
         const unsigned int want = (unsigned int)knob("OEM_TILE_EXP", 0);
-        if (want != current) {
+        std::lock_guard<std::mutex> lk(mu);
+        unsigned int &cur = current[s->device >= 0 && s->device < 64 ? s->device : 0];
+        if (want != cur) {
             OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_exp), &want, sizeof(want)));
-            current = want;
+            cur = want;
         }
     }
 #endif

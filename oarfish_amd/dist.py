@@ -165,6 +165,13 @@ class Comm:
         2 = two-phase (reduce-scatter + all-gather over the mapped buffers)."""
         _lib.check(_lib.lib().oem_comm_set_option(self.handle, _lib.OEM_COMM_OPT_P2P_SHAPE, int(shape)))
 
+    def info(self, key: int) -> int:
+        """oem_comm_info: _lib.OEM_COMM_INFO_RANKS / _RCCL_RANKS (what ncclCommCount reports) / _P2P_CONNECTED."""
+        import ctypes as C
+        v = C.c_uint64(0)
+        _lib.check(_lib.lib().oem_comm_info(self.handle, int(key), C.byref(v)))
+        return int(v.value)
+
     def close(self):
         if self.handle is not None and self.handle.value:
             _lib.lib().oem_comm_destroy(self.handle)
@@ -229,8 +236,6 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
         if p2p_capacity <= 0:
             raise ValueError("p2p_capacity (doubles per exchange buffer) is required for the peer-to-peer backend")
         blob = (C.c_ubyte * _lib.OEM_P2P_HANDLE_BYTES)()
-        if p2p_self_check and world > 1:   # (ranks are processes here: all of them are inside connect together)
-            _lib.check(L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_SELF_CHECK, 1))
         if p2p_timeout_ms:
             _lib.check(L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_TIMEOUT_MS, int(p2p_timeout_ms)))
         rc = L.oem_comm_p2p_export(h, int(p2p_capacity), C.addressof(blob))
@@ -242,6 +247,12 @@ def create_comm(rank: int, world: int, device: int, backend: str = "rccl", p2p_c
             rc = L.oem_comm_p2p_connect(h, blobs)
             err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
             oks = _gather_bytes(bytes([1 if rc == _lib.OEM_OK else 0]), rank, world, device)
+            if all(oks) and p2p_self_check and world > 1:
+                # every rank has mapped its peers: only now the checked first exchange (a rank that failed to connect
+                # would otherwise leave the others waiting in a kernel for the rendezvous bound)
+                rc = L.oem_comm_set_option(h, _lib.OEM_COMM_OPT_P2P_SELF_CHECK, 2)
+                err = L.oem_last_error().decode("utf-8", "replace") if rc != _lib.OEM_OK else ""
+                oks = _gather_bytes(bytes([1 if rc == _lib.OEM_OK else 0]), rank, world, device)
         comm.p2p = bool(all(oks))
         if not comm.p2p:   # the first failing rank's message, on every rank (the parsed bench line shows why RCCL carried the run)
             raw = (f"rank {rank}: {err}" if err else "").encode("utf-8", "replace")[:240].ljust(240, b"\0")

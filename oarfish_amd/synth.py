@@ -68,8 +68,18 @@ def _genes(n_txps: int, rng: np.random.Generator):
     return starts, sizes.astype(np.int64), gene_of
 
 
+def _families(n_genes: int, rng: np.random.Generator, adjacent: bool):
+    """Paralog families of three genes: consecutive triples of a random permutation of the genes (scattered over the
+    annotation, as an annotation numbers them), or of the genes in id order (``adjacent``: the numbering a co-mapping
+    renumbering at store creation would produce).  Returns (order, pos): family f = order[3 f : 3 f + 3], pos = inverse."""
+    order = np.arange(n_genes, dtype=np.int64) if adjacent else rng.permutation(n_genes).astype(np.int64)
+    pos = np.empty(n_genes, dtype=np.int64)
+    pos[order] = np.arange(n_genes, dtype=np.int64)
+    return order, pos
+
+
 def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_size, gene_of,
-           coverage: bool, gaps: str = "geometric"):
+           coverage: bool, gaps: str = "geometric", fam=None):
     rng = np.random.default_rng([seed, c])
     # primary transcript ~ Categorical(a)
     t0 = np.searchsorted(cdf, rng.random(n), side="right").astype(np.int64)
@@ -99,7 +109,16 @@ def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_
     spill = np.where(spill >= n_txps, gs - 1 - (spill - n_txps), spill)
     in_gene = np.where(i < gz - 1, gs + member, spill)
     in_gene = np.clip(in_gene, 0, n_txps - 1)
-    anywhere = rng.integers(0, n_txps, size=tot)
+    if fam is None:
+        anywhere = rng.integers(0, n_txps, size=tot)
+    else:
+        # far hits recur: a transcript of another gene of the read's paralog family (three genes), not anywhere
+        order, pos = fam
+        n_genes = len(order)
+        ps = pos[g]
+        other = 3 * (ps // 3) + (ps % 3 + 1 + rng.integers(0, 2, size=tot)) % 3
+        g2 = order[np.minimum(other, n_genes - 1)]
+        anywhere = g_start[g2] + (rng.random(tot) * g_size[g2]).astype(np.int64)
     t = np.where(is_gene, in_gene, anywhere)
     t[is_primary] = t0
     # score deficits d (best - s): 0 for the primary, truncated geometric otherwise
@@ -134,23 +153,31 @@ def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_
 
 
 def make_store(n_reads: int, n_txps: int, kbar: float = 8.0, seed: int = BASE_SEED,
-               coverage: bool = False, threads: int = 8, gaps: str = "geometric") -> SyntheticStore:
+               coverage: bool = False, threads: int = 8, gaps: str = "geometric", far: str = "uniform") -> SyntheticStore:
     """``gaps``: "geometric" (score deficits Geom(0.15), best score 500..3000 -- ~100 distinct
     weights) or "uniform" (long reads: deficits uniform on [0, 0.05 best], best score 500..20 000 -- ~520 distinct
-    weights; see _chunk)."""
+    weights; see _chunk).
+    ``far``: where a read's alignments outside its gene go (20 % of the non-primary ones): "uniform" -- anywhere in the
+    annotation, SURVEY.md section 8d's generator and the BASELINE headline; "paralog" -- a transcript of another gene of
+    the read's paralog FAMILY (three genes scattered over the annotation): far hits recur, as multi-mapping reads'
+    do; "paralog_adjacent" -- the same families numbered next to each other (the annotation a co-mapping renumbering
+    of the transcripts at store creation would produce)."""
     if gaps not in ("geometric", "uniform"):
         raise ValueError("gaps must be 'geometric' or 'uniform'")
+    if far not in ("uniform", "paralog", "paralog_adjacent"):
+        raise ValueError("far must be 'uniform', 'paralog' or 'paralog_adjacent'")
     rng0 = np.random.default_rng([seed, 0xA11CE])
     a = rng0.lognormal(0.0, 2.0, size=n_txps)
     a /= a.sum()
     cdf = np.cumsum(a)
     cdf /= cdf[-1]
     g_start, g_size, gene_of = _genes(n_txps, rng0)
+    fam = None if far == "uniform" else _families(len(g_start), np.random.default_rng([seed, 0xFA111E5]), far == "paralog_adjacent")
     n_chunks = (n_reads + CHUNK - 1) // CHUNK
     sizes = [min(CHUNK, n_reads - c * CHUNK) for c in range(n_chunks)]
 
     def run(c):
-        return _chunk(c, sizes[c], seed, n_txps, kbar, cdf, g_start, g_size, gene_of, coverage, gaps)
+        return _chunk(c, sizes[c], seed, n_txps, kbar, cdf, g_start, g_size, gene_of, coverage, gaps, fam)
 
     if n_chunks > 1 and threads > 1:
         with ThreadPoolExecutor(max_workers=threads) as ex:

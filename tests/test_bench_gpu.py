@@ -84,7 +84,14 @@ def test_bench_two_ranks_on_one_device_over_p2p():
     ex = d["config"]["exchange"]
     assert ex["p2p_connected"] and ex["allreduce_us"] > 0 and ex["backend"].startswith("p2p")
     for shape in ("p2p one-shot", "p2p two-phase"):   # both shapes reproduced each other and were timed
-        assert ex["candidates"][shape]["ok"] and ex["candidates"][shape]["iteration_us"] > 0
+        c = ex["candidates"][shape]
+        assert c["ok"] and c["iteration_us"] > 0
+        # the curve explains itself: the rank-local compute, the exchange alone and the sharded iteration side by side
+        assert c["shard_compute_us"] > 0 and c["exchange_us"] > 0
+        assert abs(c["iteration_minus_compute_us"] - (c["iteration_us"] - c["shard_compute_us"])) < 1e-6
+    assert abs(ex["shard_compute_us"] - max(ex["shard_compute_us_per_rank"])) < 0.01 and len(ex["shard_compute_us_per_rank"]) == 2
+    assert min(ex["shard_compute_us_per_rank"]) > 0
+    assert ex["ranks"] == 2 and ex["rccl_ranks_seen"] == 0 and ex["p2p_connected_this_rank"]   # (--same-device: no RCCL)
     assert d["bootstraps"]["n"] == 6 and d["bootstraps"]["value"] > 0 and "replica-parallel over 2" in d["bootstraps"]["mode"]
     assert d["cells"]["n_cells"] == 8 and d["cells"]["worst_mass_error"] < 1e-6 * d["cells"]["reads_per_cell"]
     for name in ("em", "em_par"):   # the sharded loop converges like the un-sharded one (tiny store: a handful of passes)
@@ -110,3 +117,21 @@ def test_bench_two_ranks_without_the_ipc_variable_in_the_environment():
     assert ex["p2p_connected"], ex                       # the variable was defaulted: hipIpc handles worked
     assert set(ex["candidate_ok"]) == set(ex["candidates"]) and all(ex["candidate_ok"].values())
     assert ex["backend"].startswith("p2p") and "p2p_not_used_because" not in ex
+
+
+@pytest.mark.timeout(1200)
+def test_run_scaling_script_on_one_device():
+    """scripts/run_scaling.sh, the N = 1, 2, 4, 8 curve of one node, exercised with all ranks on cuda:0 (SAME_DEVICE=1:
+    a self test of the launch lines, the JSON lines and the table, not scaling)."""
+    out = os.path.join(ROOT, "gpurun_out", "scaling_selftest")
+    env = dict(os.environ, SAME_DEVICE="1")
+    p = subprocess.run(["bash", "scripts/run_scaling.sh", out, "--workload", "tiny", "--bootstraps", "0", "--cells", "0",
+                        "--no-cpu-baseline", "--no-f32-compare"], cwd=ROOT, capture_output=True, text=True, timeout=1100, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    for n in (1, 2, 4, 8):
+        assert f"N={n} rc=0" in p.stdout, p.stdout[-2000:]
+        d = _last_json(open(os.path.join(out, f"scale_{n}.json")).read())
+        assert d["n_gpus"] == n and d["value"] > 0
+        if n > 1:
+            assert d["config"]["exchange"]["shard_compute_us"] > 0
+    assert "shard compute us" in p.stdout and "candidates" in p.stdout
