@@ -34,7 +34,7 @@ SOURCES = ["oem_api.hip", "oem_em_driver.hip", "oem_bootstrap.hip", "oem_cells.h
 # the testing library swaps these for their -DOEM_TESTING build and adds the hooks
 TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip", "oem_tile_pipe.hip", "oem_batch_kernels.hip"]
 TESTING_ONLY = ["oem_testing.hip"]
-HEADERS = ["oem_internal.h", "oem_driver.h", "oem_layout.h", "oem_tile_common.h", os.path.join(INCLUDE, "oarfish_em.h")]
+HEADERS = ["oem_internal.h", "oem_driver.h", "oem_layout.h", "oem_tile_common.h", "oem_lane_runs.h", os.path.join(INCLUDE, "oarfish_em.h")]
 
 FLAGS = [
     "--offload-arch=gfx950",

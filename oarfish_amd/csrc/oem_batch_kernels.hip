@@ -41,6 +41,7 @@
 #include <atomic>
 
 #include "oem_internal.h"
+#include "oem_lane_runs.h"
 
 namespace oem {
 
@@ -635,13 +636,17 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
         }
     };
     auto consume = [&](const D2 (&v)[kFoldDepth], const uint32_t (&d)[kFoldDepth], uint32_t o) {
+        // hot destinations: runs of equal ones are summed on the vector ALU first (oem_lane_runs.h; lanes 2 i and 2 i + 1
+        // hold the two halves of entry i, so a run's lanes are two apart)
+        const bool rep = keys_repeat<2>(d[0]);
 #pragma unroll
         for (int k = 0; k < kFoldDepth; ++k) {
-            if (o + k * kEntriesPerStep < s1) {
-                double *a = &acc[d[k] * kFS + 2 * half];
-                if (v[k].x != 0.0) lds_add(a, v[k].x);
-                if (v[k].y != 0.0) lds_add(a + 1, v[k].y);
-            }
+            const bool in = o + k * kEntriesPerStep < s1;
+            double xy[2] = {in ? v[k].x : 0.0, in ? v[k].y : 0.0};
+            if (rep) sum_runs_of_equal_keys<2, 2>(d[k], xy);
+            double *a = &acc[d[k] * kFS + 2 * half];
+            if (xy[0] != 0.0) lds_add(a, xy[0]);
+            if (xy[1] != 0.0) lds_add(a + 1, xy[1]);
         }
     };
     D2 va[kFoldDepth], vb[kFoldDepth];

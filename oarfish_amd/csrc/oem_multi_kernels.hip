@@ -8,6 +8,7 @@
 //   RUNNING -(em.rs:212 stopping rule / em.rs:181 max_iter)-> FINAL (em.rs:238-242 zero
 //   small, em.rs:245-252 one more pass) -> FINISHED (counts parked in `out`).
 #include "oem_internal.h"
+#include "oem_lane_runs.h"
 
 namespace oem {
 
@@ -108,10 +109,13 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
             v[k] = __builtin_nontemporal_load(&queue[oc]); // (read once: the abundances and counts keep the caches)
             d[k] = __builtin_nontemporal_load(&q_dst[oc]);
         }
+        const bool rep = keys_repeat(d[0]); // hot destinations: runs of equal ones summed on the vector ALU first (oem_lane_runs.h)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (o + k * kFT < q1 && v[k] != 0.0)
-                __hip_atomic_fetch_add(&acc[d[k]], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int k = 0; k < 4; ++k) {
+            double vk[1] = {o + k * kFT < q1 ? v[k] : 0.0};
+            if (rep) sum_runs_of_equal_keys<1, 1>(d[k], vk);
+            if (vk[0] != 0.0) __hip_atomic_fetch_add(&acc[d[k]], vk[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     __syncthreads();
     // the counts and abundances of this thread's window entries: requested together, then swept

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "oem_internal.h"
+#include "oem_lane_runs.h"
 
 #ifndef OEM_EXP
 #define OEM_EXP(bit) false // cost-attribution switches: only the test-only build of oem_tile_kernels.hip defines them

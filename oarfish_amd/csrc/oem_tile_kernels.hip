@@ -355,9 +355,15 @@ __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
             v[k] = ld_stream<kNTQ>(&queue[oc]);
             d[k] = ld_stream<kNTQ>(&q_dst[oc]);
         }
+        // hot destinations: runs of equal ones are summed on the vector ALU first (see sum_runs_of_equal_keys; one
+        // look at the trip's first entries decides for the trip: hot runs are thousands of entries long)
+        const bool rep = keys_repeat(d[0]);
 #pragma unroll
-        for (int k = 0; k < kDepth; ++k)
-            if (o + k * kFoldThreads < s1 && v[k] != 0.0) lds_add_f64(&acc[d[k]], v[k]);
+        for (int k = 0; k < kDepth; ++k) {
+            double vk[1] = {o + k * kFoldThreads < s1 ? v[k] : 0.0};
+            if (rep) sum_runs_of_equal_keys<1, 1>(d[k], vk);
+            if (vk[0] != 0.0) lds_add_f64(&acc[d[k]], vk[0]);
+        }
     }
     __syncthreads();
     const uint32_t base = b * kBucket;

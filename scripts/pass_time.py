@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HIP-event time of one E/M pass and of one loop iteration on a BASELINE-shaped store (A/B target).
-usage: pass_time.py [c3|c2] [geometric|uniform|coverage] [weight_coding 0|1]"""
+usage: pass_time.py [c3|c2] [geometric|uniform|coverage|paralog|paralog_adjacent] [weight_coding 0|1]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _ab  # noqa: E401,E402,F401  (OEM_AB_DIR: A/B against a snapshot build)
@@ -17,6 +17,8 @@ if kind == "coverage":
     st = synth.make_store(coverage=True, threads=16, **cfg)
 elif kind == "uniform":
     st = synth.make_store(gaps="uniform", threads=16, **cfg)
+elif kind in ("paralog", "paralog_adjacent"):
+    st = synth.make_store(far=kind, threads=16, **cfg)
 else:
     st = synth.make_config(wl)
 with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob if kind == "coverage" else None, st.n_txps, weight_coding=coding) as d:

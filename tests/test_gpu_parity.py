@@ -1561,3 +1561,40 @@ def test_cells_of_odd_shapes_through_the_compacted_store(T, n_cells, reads, kmax
         want, wi = c_oracle.do_em(o, max_iter=100, conv_thresh=1e-3, min_iter_gate=50)
         assert abs(infos[c].niter - wi.niter) <= 1
         assert_counts_close(out[c], want, reads, T, RTOL if infos[c].niter != wi.niter else 1e-8, f"T={T} cell {c}")
+
+
+@pytest.mark.parametrize("far", ["paralog", "paralog_adjacent"])
+def test_recurring_far_alignments_match_oracle(far):
+    """Far alignments that RECUR (a read's hits outside its gene go to the other genes of its paralog family, not
+    anywhere): the queue ranges of the fold kernels are then runs of equal destinations, which a wavefront sums across
+    its lanes before it touches the LDS (oem_lane_runs.h) -- in k_remote_fold, k_remote_fold_b (batched bootstrap) and
+    k_multi_fold_reldiff (per-cell batch).  Hot families: 300 k reads over 3 000 transcripts."""
+    st = synth.make_store(300_000, 3_000, seed=23, far=far)
+    T = st.n_txps
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    theta = np.random.default_rng(6).lognormal(0, 1.5, T)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as d:
+        n_remote = d.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS)
+        assert (n_remote == 0) == (far == "paralog_adjacent") or T < 600, n_remote
+        m = d.m_step(theta)
+        cnt, info = d.em_run(None, 200, 1e-3, 50)
+        W = np.stack([d.bootstrap_weights(9, 0), d.bootstrap_weights(9, 1), np.ones(st.n_reads, dtype=np.uint32)])
+        bout, binfo = d.bootstrap(3, row_w_all=W, max_iter=60, conv_thresh=1e-3)
+    assert_counts_close(m, c_oracle.m_step(o, theta), st.n_reads, T, 1e-10, f"m_step, {far}")
+    want, wi = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3)
+    assert info.niter == wi.niter
+    assert_counts_close(cnt, want, st.n_reads, T, 1e-9, f"em, {far}")
+    for b in range(3):
+        wb, wbi = c_oracle.do_em(o, row_w=W[b], max_iter=60, conv_thresh=1e-3)
+        assert binfo[b].niter == wbi.niter
+        assert_counts_close(bout[b], wb, st.n_reads, T, 1e-9, f"batched bootstrap {b}, {far}")
+    # the per-cell batch: 6 cells of the same shape
+    cells = [synth.make_store(40_000, 3_000, seed=100 + c, far=far) for c in range(6)]
+    cell_off = np.concatenate([[0], np.cumsum([c.n_reads for c in cells])]).astype(np.uint64)
+    row_ptr = np.concatenate([[0]] + [c.row_ptr[1:] + sum(x.nnz for x in cells[:i]) for i, c in enumerate(cells)]).astype(np.uint64)
+    tid = np.concatenate([c.tid for c in cells]); p = np.concatenate([c.as_prob for c in cells])
+    out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=120, convergence_thresh=1e-3)
+    for c, cs in enumerate(cells):
+        wc, wci = c_oracle.do_em(c_oracle.Store(cs.row_ptr, cs.tid, cs.as_prob, None, T), max_iter=120, conv_thresh=1e-3)
+        assert infos[c].niter == wci.niter
+        assert_counts_close(out[c], wc, cs.n_reads, T, 1e-9, f"cell {c}, {far}")
