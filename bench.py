@@ -216,7 +216,7 @@ def kernel_source_sha():
     """Identifies the kernels a traffic file was measured on: sha256 over the sources of the E/M and bootstrap kernels."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_layout.h"):
+    for f in ("oem_tile_kernels.hip", "oem_tile_common.h", "oem_lane_runs.h", "oem_batch_kernels.hip", "oem_layout.h"):
         with open(os.path.join(ROOT, "oarfish_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -224,10 +224,10 @@ def kernel_source_sha():
 
 def hbm_traffic(workload):
     """HBM bytes of one pass from the rocprofv3 PMC passes of this same command (collected by
-    scripts/collect_r04.sh; FETCH_SIZE corrected by the calibration recorded beside it).  The counters are not
+    scripts/collect_r05.sh; FETCH_SIZE corrected by the calibration recorded beside it).  The counters are not
     collected inside the run, so the file names the kernel sources it was measured on: `stale` says whether they have
     changed since."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
         if os.path.exists(tj):
             j = json.load(open(tj))
@@ -609,7 +609,7 @@ def bootstrap_leg(args, cfg, full, store, dist_mode, rank, world, local_rank, sy
                 ach = nbytes / (ms * 1e-3) / 1e9
                 traffic, tsrc = None, None
                 tj = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_boot_hbm_traffic.json")
-                                      for tag in ("r04", "r03", "r02")) if os.path.exists(q)), "")
+                                      for tag in ("r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
                 tstale = None
                 if tj:   # PMC passes of the same kernels (scripts/collect_pmc_cmd.sh on scripts/boot_passes.py)
                     j = json.load(open(tj))

@@ -19,7 +19,7 @@ def kernel_source_sha():
     """The kernel sources the counters were collected on (bench.py compares it with the tree it runs in)."""
     root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("oem_tile_kernels.hip", "oem_batch_kernels.hip", "oem_layout.h"):
+    for f in ("oem_tile_kernels.hip", "oem_tile_common.h", "oem_lane_runs.h", "oem_batch_kernels.hip", "oem_layout.h"):
         with open(os.path.join(root_dir, "oarfish_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
