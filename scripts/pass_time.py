@@ -26,5 +26,5 @@ with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob if kind == "coverag
     pm = min(d.time_m_step(50) for _ in range(3))
     it = min(d.time_em_iters(100) for _ in range(3)) / 100
     hbm, alg = d.bytes()
-    print(f"{wl} {kind} coding={coding} dict={d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)}: pass {pm:.4f} ms ({alg / pm / 1e6:.0f} GB/s, "
+    print(f"{wl} {kind} coding={coding} dict={d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)} remote={d.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS)}: pass {pm:.4f} ms ({alg / pm / 1e6:.0f} GB/s, "
           f"{alg / pm / 1e6 / 8000:.3f} of 8 TB/s), iteration {it:.4f} ms")
