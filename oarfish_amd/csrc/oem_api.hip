@@ -443,9 +443,20 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
         if (e == hipSuccess && compact) {
             // (see k_cells_mark: a cell keeps the transcripts that occur in it, every cell as many ids as the
             // fullest one)
-            e = hipMalloc((void **)&s->multi.rank, sizeof(uint32_t) * n_rank);
+            e = knob("OEM_TEST_FAIL_RANK_ALLOC", 0) ? hipErrorOutOfMemory : hipMalloc((void **)&s->multi.rank, sizeof(uint32_t) * n_rank);
             if (e == hipSuccess) e = hipMalloc((void **)&d_counts, sizeof(uint32_t) * relabel->n_cells);
-            if (e == hipSuccess) e = hipMemsetAsync(s->multi.rank, 0, sizeof(uint32_t) * n_rank, s->stream);
+            if (e == hipErrorOutOfMemory) { // no room for the rank table: the batch keeps every cell's full id range
+                hipFree(s->multi.rank);
+                s->multi.rank = nullptr;
+                hipFree(d_counts);
+                d_counts = nullptr;
+                (void)hipGetLastError();
+                e = hipSuccess;
+                compact = false;
+            }
+        }
+        if (e == hipSuccess && compact) {
+            e = hipMemsetAsync(s->multi.rank, 0, sizeof(uint32_t) * n_rank, s->stream);
             std::vector<uint32_t> counts(relabel->n_cells);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_cells_mark, rgrid, dim3(256), 0, s->stream, (const uint32_t *)m.row_ptr, m.tid, d_off,

@@ -167,11 +167,26 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             tm.lap("cells: EM loop");
             const double *d_res = mb.out;
             double *d_full = nullptr;
-            if (compacted) { // expand to the caller's [cell][transcript] (the queue is done with: its memory is free by now)
-                if (hipMalloc((void **)&d_full, sizeof(double) * full_total) != hipSuccess) {
-                    rc2 = fail(OEM_ERR_OOM, "oem_em_run_cells: no device memory for the expanded results");
+            bool expanded_on_host = false;
+            if (compacted && (knob("OEM_TEST_FAIL_FULL_ALLOC", 0) || hipMalloc((void **)&d_full, sizeof(double) * full_total) != hipSuccess)) {
+                // no device memory for the expanded results: the compact ones and the rank table go to the host,
+                // which expands them (a transcript that does not occur in a cell is 0)
+                (void)hipGetLastError();
+                d_full = nullptr;
+                const size_t n_eff = (size_t)mb.n_problems * mb.txps_eff;
+                std::vector<double> h_eff(n_eff);
+                std::vector<uint32_t> h_rank((size_t)full_total);
+                if (hipMemcpy(h_eff.data(), mb.out, sizeof(double) * n_eff, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(h_rank.data(), mb.rank, sizeof(uint32_t) * full_total, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(hs.data(), mb.state, sizeof(BatchState) * n_cells, hipMemcpyDeviceToHost) != hipSuccess) {
+                    rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: read-back failed");
                     break;
                 }
+                for (size_t i = 0; i < (size_t)full_total; ++i)
+                    out[i] = h_rank[i] == kNoRank ? 0.0 : h_eff[(i / mb.txps_full) * mb.txps_eff + h_rank[i]];
+                expanded_on_host = true;
+            }
+            if (compacted && !expanded_on_host) { // expand to the caller's [cell][transcript] (the queue is done with: its memory is free by now)
                 if ((rc2 = launch_multi_expand(s, mb, d_full)) != OEM_OK || hipStreamSynchronize(s->stream) != hipSuccess) {
                     hipFree(d_full);
                     if (rc2 == OEM_OK) rc2 = fail(OEM_ERR_HIP, "oem_em_run_cells: expanding the results failed");
@@ -179,7 +194,7 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
                 }
                 d_res = d_full;
             }
-            const bool copied = hipMemcpy(out, d_res, sizeof(double) * full_total, hipMemcpyDeviceToHost) == hipSuccess;
+            const bool copied = expanded_on_host || hipMemcpy(out, d_res, sizeof(double) * full_total, hipMemcpyDeviceToHost) == hipSuccess;
             hipFree(d_full);
             if (!copied ||
                 hipMemcpy(hs.data(), mb.state, sizeof(BatchState) * n_cells, hipMemcpyDeviceToHost) != hipSuccess) {

@@ -1598,3 +1598,22 @@ def test_recurring_far_alignments_match_oracle(far):
         wc, wci = c_oracle.do_em(c_oracle.Store(cs.row_ptr, cs.tid, cs.as_prob, None, T), max_iter=120, conv_thresh=1e-3)
         assert infos[c].niter == wci.niter
         assert_counts_close(out[c], wc, cs.n_reads, T, 1e-9, f"cell {c}, {far}")
+
+
+@pytest.mark.parametrize("knob", ["OEM_TEST_FAIL_RANK_ALLOC", "OEM_TEST_FAIL_FULL_ALLOC"])
+def test_cells_survive_a_failed_allocation_of_the_compaction_buffers(knob, monkeypatch):
+    """The per-cell transcript compaction needs a rank table (cells x transcripts u32) and, on the way out, a buffer for
+    the expanded results.  Without room for the first the batch keeps every cell's full id range; without room for the
+    second the host expands the compact results (test-only library: the knobs make the allocations fail)."""
+    n_cells, T = 7, 900
+    cell_off, row_ptr, tid, p = synth.make_cells(n_cells, 3_000, T, seed=31, expressed_frac=0.2)
+    want, winfos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=200, convergence_thresh=1e-3)
+    monkeypatch.setenv(knob, "1")
+    with _lib.testing():
+        got, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, T, max_iter=200, convergence_thresh=1e-3)
+    for c in range(n_cells):
+        assert infos[c].niter == winfos[c].niter
+        assert_counts_close(got[c], want[c], int(cell_off[c + 1] - cell_off[c]), T, 1e-9, f"cell {c}, {knob}")
+    o = c_oracle.Store(row_ptr[:int(cell_off[1]) + 1], tid[:int(row_ptr[int(cell_off[1])])], p[:int(row_ptr[int(cell_off[1])])], None, T)
+    w0, _ = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3)
+    assert_counts_close(got[0], w0, int(cell_off[1]), T, 1e-9, "cell 0 vs the oracle")
