@@ -21,7 +21,7 @@
 // per-phase account of profiles/r03_notes.md.  The product build has no probe code at all.
 // Cost attribution (test-only library, OEM_TILE_EXP): parts of the kernel switched off -- wrong results, the time
 // says what the part costs.  1 queue stores, 2 remote denominator atomics, 4 local scatter atomics, 8 local theta
-// reads, 16 remote theta gathers
+// reads, 16 remote theta gathers, 32 window flush as plain stores, 64 no window flush
 #ifdef OEM_TESTING
 #define OEM_PROBE(i)                                                                                          \
     do {                                                                                                      \
@@ -308,7 +308,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     for (uint32_t i = tx; i < td.win_len; i += kTileThreads) {
         double v = 0.0;
         for (uint32_t p = 0; p < (1u << cs); ++p) v += cnt_l[(i << cs) + ((p + lane) & ((1u << cs) - 1u))];
-        if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
+        if (OEM_EXP(32u)) { if (v != 0.0) cnt[td.lo + i] = v; }      // (cost attribution: the flush as plain stores)
+        else if (OEM_EXP(64u)) { if (v == -1.0) cnt[td.lo + i] = v; } // (... and not at all)
+        else if (v != 0.0) unsafeAtomicAdd(&cnt[td.lo + i], v);
     }
     OEM_PROBE(11); // queue stores and window flush issued
 }

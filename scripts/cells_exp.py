@@ -13,7 +13,7 @@ n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 625
 cell_off, row_ptr, tid, p = synth.make_cells(n_cells, 50_000, 60_000, seed=3, threads=min(32, os.cpu_count() or 4))
 _lib.testing().__enter__()
 _lib.lib()
-for mask in (0, 1, 16, 4, 8, 2, 19, 31):
+for mask in [int(m) for m in os.environ.get('OEM_EXP_MASKS', '0,1,16,4,8,2,19,31').split(',')]:
     os.environ["OEM_TILE_EXP"] = str(mask)
     out, infos = oarfish_amd.em_cells(cell_off, row_ptr, tid, p, None, 60_000, max_iter=100, convergence_thresh=0.0)
     ms, passes = cells_last_timing()
