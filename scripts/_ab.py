@@ -16,6 +16,33 @@ if _d:
     print(f"[ab] libraries from {_d}", file=sys.stderr)
 
 
+def _cache_dir(n_reads, n_txps, kbar, seed, coverage, kw):
+    import hashlib
+    from oarfish_amd import synth
+    src = open(synth.__file__, "rb").read()
+    key = hashlib.sha1(repr((n_reads, n_txps, kbar, seed, coverage, sorted(kw.items()))).encode() + src).hexdigest()[:16]
+    return os.path.join(os.environ.get("OEM_SYNTH_CACHE", "/tmp/oem_synth_cache"), key)
+
+
+_NAMES = ["row_ptr", "tid", "as_prob", "cov_prob", "abundance", "gene_of"]
+
+
+def put_store(st, n_reads, n_txps, kbar=8.0, seed=None, coverage=False, **kw):
+    """Hand a store this process has generated to the measurement scripts it is about to start as children
+    (bench.py's live HBM-traffic passes): written where make_store's cache looks for it."""
+    import numpy as np
+    from oarfish_amd import synth
+    d = _cache_dir(n_reads, n_txps, kbar, synth.BASE_SEED if seed is None else seed, coverage, kw)
+    if os.path.exists(os.path.join(d, "done")):
+        return d
+    os.makedirs(d, exist_ok=True)
+    for n, a in zip(_NAMES, [st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.abundance, st.gene_of]):
+        if a is not None:
+            np.save(os.path.join(d, n + ".npy"), a)
+    open(os.path.join(d, "done"), "w").close()
+    return d
+
+
 # The synthetic stores take longer to generate than to measure (C3: ~30 s on the box's 16 CPUs): the scripts of
 # one gpurun call share them through /tmp (keyed by the generator's arguments).
 def _cached_make_store():
@@ -27,10 +54,8 @@ def _cached_make_store():
     def make_store(n_reads, n_txps, kbar=8.0, seed=synth.BASE_SEED, coverage=False, threads=8, **kw):
         if n_reads < 500_000 or os.environ.get("OEM_NO_SYNTH_CACHE"):
             return orig(n_reads, n_txps, kbar, seed=seed, coverage=coverage, threads=threads, **kw)
-        src = open(synth.__file__, "rb").read()
-        key = hashlib.sha1(repr((n_reads, n_txps, kbar, seed, coverage, sorted(kw.items()))).encode() + src).hexdigest()[:16]
-        d = os.path.join(os.environ.get("OEM_SYNTH_CACHE", "/tmp/oem_synth_cache"), key)
-        names = ["row_ptr", "tid", "as_prob", "cov_prob", "abundance", "gene_of"]
+        d = _cache_dir(n_reads, n_txps, kbar, seed, coverage, kw)
+        names = _NAMES
         if os.path.exists(os.path.join(d, "done")):
             arrs = [np.load(os.path.join(d, n + ".npy")) if os.path.exists(os.path.join(d, n + ".npy")) else None for n in names]
             return synth.SyntheticStore(arrs[0], arrs[1], arrs[2], arrs[3], n_txps, arrs[4], arrs[5])

@@ -4,7 +4,7 @@
 tag=${1:-r01}; wl=${2:-c3}
 out=gpurun_out/pmc_sq; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --bootstraps 0 --cells 0"
+B="python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --no-live-traffic --bootstraps 0 --cells 0"
 i=0
 for set in "GRBM_GUI_ACTIVE GRBM_TA_BUSY GRBM_EA_BUSY GRBM_TC_BUSY" "TCC_BUSY_avr TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE" \
