@@ -155,6 +155,8 @@ void free_store(oem_store *s)
     hipFree(s->multi.rank);
     hipFree(s->theta);
     hipFree(s->cnt);
+    hipFree(s->third);
+    hipFree(s->rel_slots);
     hipFree(s->d_state);
     hipFree(s->d_row_w);
     if (s->h_state) hipHostFree(s->h_state);

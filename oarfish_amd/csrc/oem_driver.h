@@ -73,6 +73,9 @@ int enqueue_pass(oem_store *s, const RunArgs &a, const EmState *state);
 int prepare_row_w(oem_store *s, const RunArgs &a);
 int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p);
 int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info);
+bool deferred_reldiff_ok(const oem_store *s, const RunArgs &a);
+int ensure_deferred(oem_store *s);
+int enqueue_deferred_pass(oem_store *s, const RunArgs &a, const EmParams &p, double *const bufs[3], uint64_t i);
 int copy_counts_out(oem_store *s, double *out);
 int ensure_row_w(oem_store *s);
 

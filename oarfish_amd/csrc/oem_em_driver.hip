@@ -41,10 +41,92 @@ int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
     return OEM_OK;
 }
 
+// ---- the stopping rule one pass behind ------------------------------------------------------------------------
+// An iteration of do_em is a pass and then a sweep over the two count vectors (rel-diff, swap, clear: em.rs:194-207)
+// whose only product is one number and a decision.  On the device that sweep is a 6 us kernel between 0.15 ms passes
+// -- 27 us passes at 1 M reads -- with a launch boundary on either side.  Here it rides on the NEXT pass: theta_{i+1}
+// simply IS the vector pass i accumulated into (no swap), the tile workgroups of pass i + 1 each compare their share
+// of theta_i and theta_{i+1} and zero their share of theta_i (it becomes the accumulator of pass i + 2: three
+// vectors rotate), and the first workgroup of pass i + 1's fold applies the rule (DeferredRelDiff, oem_internal.h).
+// If it says stop, pass i + 1 was speculative and its accumulator is dropped: the loop has run the reference's
+// iterations, stopped where the reference stops, and theta is what the reference holds at that point; the cost is one
+// pass per run.  Single-device stores on the tiled path; row shards keep the sweep (it carries their exchange).
+bool deferred_reldiff_ok(const oem_store *s, const RunArgs &a)
+{
+    return use_tiled(s, a) && !comm_exchanges(s->comm) && !graph_ok(s) && knob("OEM_DEFERRED_RELDIFF", 1) != 0;
+}
+
+int ensure_deferred(oem_store *s)
+{
+    if (!s->third) OEM_TRY(dev_alloc(&s->third, s->csr.n_txps, &s->hbm_bytes));
+    if (!s->rel_slots) OEM_TRY(dev_alloc(&s->rel_slots, kRelSlots, &s->hbm_bytes));
+    return OEM_OK;
+}
+
+// pass i of a deferred run: theta_i in bufs[i % 3], accumulator bufs[(i + 1) % 3], theta_{i-1} in bufs[(i + 2) % 3]
+int enqueue_deferred_pass(oem_store *s, const RunArgs &a, const EmParams &p, double *const bufs[3], uint64_t i)
+{
+    DeferredRelDiff rd{i > 0 ? bufs[(i + 2) % 3] : nullptr, s->rel_slots, s->d_state, p, 1u + (uint32_t)(i % 3)};
+    return launch_em_pass_tiled(s, bufs[i % 3], bufs[(i + 1) % 3], s->d_state, a.d_row_w ? s->tiled.row_w_perm : nullptr,
+                                nullptr, 0, false, &rd);
+}
+
+static int run_em_deferred(oem_store *s, const RunArgs &a, oem_run_info *info)
+{
+    const uint32_t T = s->csr.n_txps;
+    EmParams p{T, a.max_iter, a.min_iter_gate, a.conv_thresh};
+    OEM_TRY(ensure_deferred(s));
+    double *const bufs[3] = {s->theta, s->cnt, s->third};
+    if (a.init) {
+        OEM_HIP(hipMemcpyAsync(bufs[0], a.init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+    } else {
+        OEM_TRY(launch_fill(s, bufs[0], (double)a.total_reads / (double)T, T)); // em.rs:165
+    }
+    OEM_HIP(hipMemsetAsync(bufs[1], 0, sizeof(double) * T, s->stream));
+    OEM_HIP(hipMemsetAsync(bufs[2], 0, sizeof(double) * T, s->stream));
+    OEM_HIP(hipMemsetAsync(s->rel_slots, 0, sizeof(unsigned long long) * kRelSlots, s->stream));
+    OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
+    std::memset(s->h_state, 0, sizeof(EmState));
+    OEM_TRY(prepare_row_w(s, a));
+    // iteration j is decided by pass j + 1: max_iter iterations take max_iter + 1 passes
+    const uint64_t n_total = a.max_iter ? (uint64_t)a.max_iter + 1 : 0;
+    uint64_t launched = 0;
+    while (launched < n_total) {
+        uint64_t chunk = launched == 0 ? (uint64_t)a.min_iter_gate + 3 : 16;
+        if (chunk > n_total - launched) chunk = n_total - launched;
+        if (chunk > 4096) chunk = 4096;
+        for (uint64_t k = 0; k < chunk; ++k) OEM_TRY(enqueue_deferred_pass(s, a, p, bufs, launched + k));
+        launched += chunk;
+        OEM_HIP(hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream));
+        OEM_HIP(hipStreamSynchronize(s->stream));
+        if (s->h_state->done) break;
+    }
+    if (n_total && !s->h_state->done) return fail(OEM_ERR_STATE, "the deferred stopping rule did not fire within max_iter + 1 passes");
+    const uint32_t f = n_total ? s->h_state->pad[0] - 1u : 0u; // the buffer of the final abundances
+    if (f > 2u) return fail(OEM_ERR_STATE, "the deferred stopping rule left no final buffer");
+    // final: em.rs:238-252.  The buffer behind theta's was zeroed by the pass that decided; the one ahead holds that
+    // pass's speculative counts and rests.
+    double *theta = bufs[f], *cnt = bufs[(f + 2) % 3], *rest = bufs[(f + 1) % 3];
+    OEM_TRY(launch_zero_small(s, theta, cnt, T));
+    s->theta = theta;
+    s->cnt = cnt;
+    s->third = rest;
+    OEM_TRY(enqueue_pass(s, a, nullptr));
+    if (info) {
+        info->niter = s->h_state->niter;
+        info->n_passes = s->h_state->n_passes + 1;
+        info->converged = s->h_state->converged;
+        info->reserved = 0;
+        info->rel_diff = s->h_state->last_rel;
+    }
+    return OEM_OK;
+}
+
 // em.rs:144-255 / :320-447 with the loop state on the device.  On return the
 // final counts are in s->cnt (device); *info filled from the device state.
 int run_em_device(oem_store *s, const RunArgs &a, oem_run_info *info)
 {
+    if (deferred_reldiff_ok(s, a)) return run_em_deferred(s, a, info);
     const uint32_t T = s->csr.n_txps;
     EmParams p{T, a.max_iter, a.min_iter_gate, a.conv_thresh};
 

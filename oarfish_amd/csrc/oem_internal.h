@@ -209,6 +209,8 @@ struct oem_store {
     // working set of one EM problem
     double *theta = nullptr;             // prev_counts, n_txps f64
     double *cnt = nullptr;               // curr_counts (rank-local partial sums until all-reduced)
+    double *third = nullptr;             // the third count vector of the deferred stopping rule (run_em_deferred), lazily
+    unsigned long long *rel_slots = nullptr; // its kRelSlots running maxima
     oem::EmState *d_state = nullptr;
     oem::EmState *h_state = nullptr;     // pinned
     uint32_t *d_row_w = nullptr;         // bootstrap multiplicities, n_reads u32
@@ -250,9 +252,23 @@ int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_
 int build_weight_dictionary(oem_store *s); // oem_layout_dict.hip
 // oem_layout_pack.hip: slot table + packed remote records, after either builder
 int pack_remote_records(oem_store *s, uint32_t problem_size, bool keep_unpacked);
+// The stopping rule one pass behind (oem_em_driver.hip: run_em_deferred).  The pass that reads theta_i = cnt_{i-1} also
+// takes the rel-diff of iteration i - 1 along: every tile workgroup compares its share of the transcripts between
+// `prev` (theta_{i-1}) and theta_i, keeps its maximum in one of kRelSlots slots and zeroes its share of `prev` (which
+// becomes the accumulator of pass i + 1); the first workgroup of the fold that follows applies the rule
+// (em.rs:212-218) to the slots' maximum.  `decide` = 0 (pass 0: nothing to decide) or 1 + the index of the buffer that
+// holds theta_i -- the final abundances if the rule says stop.
+constexpr uint32_t kRelSlots = 64;
+struct DeferredRelDiff {
+    double *prev;              // theta_{i-1}; NULL on pass 0
+    unsigned long long *slots; // kRelSlots running maxima (bit patterns of non-negative doubles)
+    EmState *state;
+    EmParams p;
+    uint32_t decide;
+};
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems = nullptr,
-                         uint32_t problem_size = 0, bool skip_fold = false);
+                         uint32_t problem_size = 0, bool skip_fold = false, const DeferredRelDiff *rd = nullptr);
 
 // oem_tile_pipe.hip: the same pass as a software pipeline over tiles (persistent workgroups), for the stores it applies to
 bool tile_pipeline_applies(const oem_store *s, const BatchState *problems);

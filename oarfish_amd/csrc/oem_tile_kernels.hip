@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     const EmState *state, const uint32_t *__restrict__ row_w_perm,
     const BatchState *__restrict__ problems, uint32_t problem_size, uint32_t n_tiles,
     const uint32_t *__restrict__ widx, const uint32_t *__restrict__ i_base, const float *__restrict__ dict,
-    const uint8_t *__restrict__ r_wi, const uint32_t *__restrict__ live_tiles)
+    const uint8_t *__restrict__ r_wi, const uint32_t *__restrict__ live_tiles,
+    double *__restrict__ rd_prev, unsigned long long *__restrict__ rd_slots, uint32_t rd_chunk, uint32_t n_txps)
 {
     __shared__ float dict_l[dict_entries<kDict>()]; // the distinct weights of a coded store (oem_layout_dict.hip)
     __shared__ double theta_l[kWinT]; // kWin, or kWinWideLds with one count-window copy (sparse stores)
@@ -161,6 +162,16 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         const uint32_t i = tx + u * kTileThreads;
         tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
     }
+    // The rel-diff of the PREVIOUS iteration rides along (DeferredRelDiff, oem_internal.h): this workgroup's share of
+    // the transcripts, theta_{i-1} against theta_i = what this pass reads as theta.  Requested with the window, looked
+    // at behind the first barrier: its atomic is long performed when the workgroup ends (at the end of the kernel it
+    // kept every workgroup alive for its round trip: +3 us per pass).
+    double rd_p = 0.0, rd_c = 0.0;
+    const uint32_t rd_i0 = blockIdx.x * rd_chunk, rd_i1 = rd_i0 + rd_chunk < n_txps ? rd_i0 + rd_chunk : n_txps;
+    if (rd_prev && rd_i0 + tx < rd_i1) {
+        rd_p = rd_prev[rd_i0 + tx];
+        rd_c = theta[rd_i0 + tx];
+    }
     constexpr uint32_t kDictPer = (dict_entries<kDict>() + kTileThreads - 1) / kTileThreads;
     float dict_v[kDictPer];
 #pragma unroll
@@ -245,6 +256,21 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
     __syncthreads();
     OEM_PROBE(3);
+    if (rd_prev && rd_i0 < rd_i1 && (tx & ~63u) < rd_i1 - rd_i0) { // wave-uniform: the wavefronts that hold a share.
+        double rel = 0.0;                                          // em.rs:194-201 (signed, floored at 0 by the maximum),
+        if (rd_i0 + tx < rd_i1) {                                  // :207 for the buffer that rests
+            if (rd_p > OEM_MIN_READ_THRESH) rel = fmax(rel, (rd_c - rd_p) / rd_p);
+            rd_prev[rd_i0 + tx] = 0.0;
+        }
+        for (uint32_t i = rd_i0 + tx + kTileThreads; i < rd_i1; i += kTileThreads) { // (more transcripts than tiles x 256)
+            const double pv = rd_prev[i], cv = theta[i];
+            if (pv > OEM_MIN_READ_THRESH) rel = fmax(rel, (cv - pv) / pv);
+            rd_prev[i] = 0.0;
+        }
+        for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+        if (lane == 0 && rel > 0.0) // (non-negative doubles order like their bit patterns; no return value: nothing waits)
+            atomicMax(&rd_slots[blockIdx.x & (kRelSlots - 1u)], (unsigned long long)__double_as_longlong(rel));
+    }
 
     // ---- remote alignments, phase A: denominators --------------------------------
 #pragma unroll
@@ -315,6 +341,41 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(11); // queue stores and window flush issued
 }
 
+// The stopping rule of the deferred rel-diff (em.rs:212-218, :181), by one wavefront: the maximum over the slots the
+// tile workgroups of this pass filled, the slots reset for the next pass.
+__device__ __forceinline__ void deferred_decide(unsigned long long *slots, EmState *state, EmParams p, uint32_t decide)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    static_assert(kRelSlots == 64, "one slot per lane");
+    unsigned long long bits = __hip_atomic_load(&slots[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slots[lane] = 0ull;                                            // em.rs:234
+    double rel = __longlong_as_double((long long)bits);
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+    if (lane != 0) return;
+    state->last_rel = rel;
+    state->n_passes += 1;
+    uint32_t niter = state->niter;
+    bool stop = false;
+    if (rel < p.conv_thresh && niter > p.min_iter_gate) {          // em.rs:212 / :399
+        state->converged = 1;
+        stop = true;
+    } else {
+        niter += 1;                                                // em.rs:218
+        state->niter = niter;
+        stop = niter >= p.max_iter;                                // em.rs:181 loop condition
+    }
+    if (stop) {
+        state->pad[0] = decide; // 1 + the buffer that holds the final abundances (theta of the pass that decides)
+        state->done = 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_deferred_decide(unsigned long long *slots, EmState *state, EmParams p, uint32_t decide)
+{
+    if (state->done) return;
+    deferred_decide(slots, state, p, decide);
+}
+
 // kNTQ: the queue range is read non-temporally.  Measured both ways (profiles/r04_notes.md): a store that fits the
 // Infinity Cache with room to spare (C2: 1 M reads) gains 2.7 % of its pass -- the entries are read once and theta and the
 // counts keep the L2 -- while at C3 the fold finds the entries the tile kernel has just written in the caches, and
@@ -323,9 +384,12 @@ template <bool kNTQ>
 __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
     const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, const EmState *state,
-    uint32_t n_groups, uint32_t n_txps, const BatchState *__restrict__ problems, uint32_t problem_size)
+    uint32_t n_groups, uint32_t n_txps, const BatchState *__restrict__ problems, uint32_t problem_size,
+    unsigned long long *rd_slots, EmState *rd_state, EmParams rd_p, uint32_t rd_decide)
 {
     if (state && state->done) return;
+    // (deferred stopping rule: the tile kernel of this pass has left the previous iteration's maxima in the slots)
+    if (rd_decide && blockIdx.x == 0 && threadIdx.x < 64) deferred_decide(rd_slots, rd_state, rd_p, rd_decide);
     __shared__ double acc[kBucket];
     const uint32_t b = blockIdx.x / n_groups, g = blockIdx.x % n_groups;
     if (problems) { // per-cell batch: skip the bucket when every cell it touches is finished
@@ -394,7 +458,7 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 // (40 KiB LDS; same-address atomics are rare when few reads share a transcript).
 template <typename WT, bool kNT, bool kPacked, int kDict>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
-                        const EmState *state, const uint32_t *row_w_perm, const BatchState *problems)
+                        const EmState *state, const uint32_t *row_w_perm, const BatchState *problems, const DeferredRelDiff *rd)
 {
     const DeviceTiled &t = s->tiled;
     const uint32_t *r_a = kPacked ? t.r_pk : t.r_tid;
@@ -403,14 +467,19 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     const uint32_t n_tiles = live_tiles ? s->multi.n_live_tiles : t.n_tiles;
     if (n_tiles == 0) return;
     const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
+    double *rd_prev = rd && !problems ? rd->prev : nullptr;
+    unsigned long long *rd_slots = rd ? rd->slots : nullptr;
+    const uint32_t n_txps = s->csr.n_txps, rd_chunk = (n_txps + grid - 1) / grid;
     if (t.win_cap > kWin)
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, (sizeof(WT) == 4 ? OEM_WAVES_WIDE : 2), 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
+                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles,
+                           rd_prev, rd_slots, rd_chunk, n_txps);
     else
         hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), OEM_COPIES, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
-                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles);
+                           row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles,
+                           rd_prev, rd_slots, rd_chunk, n_txps);
 }
 
 static uint32_t fold_groups(const DeviceTiled &t)
@@ -429,7 +498,8 @@ static uint32_t fold_groups(const DeviceTiled &t)
 }
 
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
-                         const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold)
+                         const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold,
+                         const DeferredRelDiff *rd)
 {
     const DeviceTiled &t = s->tiled;
     if (t.n_tiles == 0) return OEM_OK;
@@ -454,12 +524,12 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     const bool nt = nt_knob < 0 ? stream_bytes > (192ull << 20) : nt_knob != 0;
 #define OEM_TILE(WT, NT, W, RW, DICT)                                                                       \
     do {                                                                                                   \
-        if (t.packed) launch_tile<WT, NT, true, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);          \
-        else launch_tile<WT, NT, false, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems);                  \
+        if (t.packed) launch_tile<WT, NT, true, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems, rd);      \
+        else launch_tile<WT, NT, false, DICT>(s, W, RW, theta, cnt, state, row_w_perm, problems, rd);              \
     } while (0)
     // (a store whose codes carry the fused index has no other way to be read; the knob -- testing build, A/B --
     // switches only the byte-stream coding off)
-    const bool pipelined = tile_pipeline_applies(s, problems); // oem_tile_pipe.hip: measured, not shipped (test-only library)
+    const bool pipelined = !rd && tile_pipeline_applies(s, problems); // oem_tile_pipe.hip: measured, not shipped (test-only library)
     if (pipelined) OEM_TRY(launch_tile_pipeline(s, theta, cnt, state, row_w_perm, nt));
     const bool coded = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
     const bool bytes = coded && !t.dict_words, words = coded && t.dict_words;
@@ -482,16 +552,23 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     }
 #undef OEM_TILE
     OEM_HIP(hipGetLastError());
+    unsigned long long *rd_slots = rd ? rd->slots : nullptr;
+    EmState *rd_state = rd ? rd->state : nullptr;
+    const EmParams rd_p = rd ? rd->p : EmParams{0, 0, 0, 0.0};
+    const uint32_t rd_decide = rd && rd->prev ? rd->decide : 0u;
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
         const uint32_t n_groups = fold_groups(t);
         if (stream_bytes > (96ull << 20)) // (2.5 M reads, 170 MB of streams: already better cached -- see kNTQ)
             hipLaunchKernelGGL(k_remote_fold<false>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
                                s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                               s->csr.n_txps, problems, problem_size);
+                               s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
         else
             hipLaunchKernelGGL(k_remote_fold<true>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
                                s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                               s->csr.n_txps, problems, problem_size);
+                               s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
+        OEM_HIP(hipGetLastError());
+    } else if (rd_decide) { // no fold to carry the decision (a store without remote alignments)
+        hipLaunchKernelGGL(k_deferred_decide, dim3(1), dim3(64), 0, s->stream, rd_slots, rd_state, rd_p, rd_decide);
         OEM_HIP(hipGetLastError());
     }
     return OEM_OK;

@@ -1617,3 +1617,35 @@ def test_cells_survive_a_failed_allocation_of_the_compaction_buffers(knob, monke
     o = c_oracle.Store(row_ptr[:int(cell_off[1]) + 1], tid[:int(row_ptr[int(cell_off[1])])], p[:int(row_ptr[int(cell_off[1])])], None, T)
     w0, _ = c_oracle.do_em(o, max_iter=200, conv_thresh=1e-3)
     assert_counts_close(got[0], w0, int(cell_off[1]), T, 1e-9, "cell 0 vs the oracle")
+
+
+@pytest.mark.parametrize("far", ["uniform", "paralog_adjacent"])
+def test_stopping_rule_one_pass_behind_stops_where_the_reference_stops(far, monkeypatch):
+    """run_em_deferred (oem_em_driver.hip): the rel-diff of iteration i rides on pass i + 1 (three count vectors rotate,
+    the fold's first workgroup -- or, for a store without remote alignments, a one-wavefront kernel -- applies
+    em.rs:212-218), so a run is the reference's iterations plus one speculative pass.  Iteration counts, rel_diff and
+    counts against the oracle and against the classic loop (sweep kernel after every pass) for both gates, caps that
+    bite at every small max_iter, a caller's init vector, a threshold nothing meets."""
+    st = synth.make_store(150_000, 6_000, seed=43, far=far)
+    T = st.n_txps
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    init = np.random.default_rng(3).lognormal(0, 1.0, T) * st.n_reads / T
+    cases = [(None, 1000, 1e-3, 50), (None, 1000, 1e-3, 1), (None, 1000, 1e-2, 1), (init, 300, 1e-3, 50), (None, 40, 0.0, 50)]
+    cases += [(None, m, 1e-3, 1) for m in (0, 1, 2, 3, 4, 5)] + [(None, 52, 1e-1, 50), (None, 53, 1e-1, 50)]
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as d:
+        assert (d.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS) == 0) == (far == "paralog_adjacent")
+        got = [d.em_run(i, m, th, g) for i, m, th, g in cases]
+        again = d.em_run(None, 1000, 1e-3, 50)          # the vectors rotate between runs: a second run from scratch
+    monkeypatch.setenv("OEM_DEFERRED_RELDIFF", "0")
+    with _lib.testing(), DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as d:
+        classic = [d.em_run(i, m, th, g) for i, m, th, g in cases]
+    for (i, m, th, g), (cnt, info), (ccnt, cinfo) in zip(cases, got, classic):
+        want, wi = c_oracle.do_em(o, init=i, max_iter=m, conv_thresh=th, min_iter_gate=g)
+        what = f"max_iter {m}, thresh {th}, gate {g}, init {'yes' if i is not None else 'no'}, {far}"
+        assert (info.niter, info.n_passes, info.converged) == (wi.niter, wi.n_passes, wi.converged), what
+        assert (cinfo.niter, cinfo.n_passes, cinfo.converged) == (wi.niter, wi.n_passes, wi.converged), what
+        assert abs(info.rel_diff - wi.rel_diff) <= 1e-9 * max(abs(wi.rel_diff), 1e-12) + 1e-15, what
+        assert_counts_close(cnt, want, st.n_reads, T, 1e-9, what)
+        assert_counts_close(cnt, ccnt, st.n_reads, T, 1e-10, "one pass behind vs the classic loop, " + what)
+    assert again[1].niter == got[0][1].niter
+    assert_counts_close(again[0], got[0][0], st.n_reads, T, 1e-12, "second run")
