@@ -375,11 +375,12 @@ def main():
     exchange = None
     shard_compute_us = None
     if dist_mode:
-        # What this rank's shard costs by itself: whole EM iterations of the un-attached shard store (tile kernel, fold,
-        # rel-diff / swap / clear, no exchange), HIP-event-timed -- beside the exchange's own time and the sharded
-        # iteration below, so that a scaling curve says which of the two did not scale (config.exchange).
-        store.time_em_iters(20)
-        shard_compute_us = store.time_em_iters(100) / 100 * 1e3
+        # What this rank's shard costs by itself: the E/M pass of the un-attached shard store (tile kernel + fold; the
+        # sweep over the count vector is part of the exchange kernels in a sharded run), HIP-event-timed -- beside the
+        # exchange's own time and the sharded iteration below, so that a scaling curve says which of the two did not
+        # scale (config.exchange).
+        store.time_m_step(20)
+        shard_compute_us = store.time_m_step(100) * 1e3
         # RCCL plus the one-shot peer-to-peer exchange for the 1.6 MB count vector (oem_p2p.hip); world 1 under
         # --force-dist: a real one-rank RCCL communicator and a one-rank exchange buffer
         comm = odist.create_comm(rank, world, local_rank, backend="p2p" if args.same_device else "both",

@@ -13,6 +13,7 @@ for n in (1, 2, 4, 8):
     a1 = int(full.row_ptr[r1])
     d = DeviceStore(full.row_ptr[:r1 + 1], full.tid[:a1], full.as_prob[:a1], None, full.n_txps)
     d.time_em_iters(20)
-    ms = d.time_em_iters(200) / 200
-    print(f"N={n}: shard {r1} reads, {a1} alignments: {ms*1e3:.1f} us per iteration (compute only) -> {1e3/ms:.0f} it/s upper bound")
+    ms = d.time_em_iters(200) / 200     # (an un-attached store: the single-device loop, stopping rule one pass behind)
+    pm = d.time_m_step(100)             # (what a row shard's iteration has before its exchange kernels: tile kernel + fold)
+    print(f"N={n}: shard {r1} reads, {a1} alignments: pass {pm*1e3:.1f} us, single-device iteration {ms*1e3:.1f} us -> {1e3/ms:.0f} it/s upper bound")
     d.close()
