@@ -5,7 +5,7 @@
 #      (what bench.py's bootstraps.roofline.kernel_avg_ms times), and the two-chain run of scripts/boot_bench.py
 #   3. SQ / TCC counters of both (scripts/collect_pmc_cmd.sh)
 #   4. the 625-cell slice
-out=gpurun_out/profiles_r05; mkdir -p $out
+out=gpurun_out/profiles_r05; rm -rf $out gpurun_out/profiles; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 bash scripts/collect_profiles.sh r05 c3 > $out/collect_c3.log 2>&1
 python scripts/hbm_traffic_json.py gpurun_out/profiles c3 $out/r05_c3_hbm_traffic.json r05 >> $out/collect_c3.log 2>&1

@@ -47,6 +47,7 @@ kern = {}
 names = ("k_em_tile_e", "k_remote_fold_b", "k_reldiff_b") if boot else ("k_em_tile", "k_remote_fold", "k_reldiff_swap_clear")
 if cells:
     names = ("k_em_tile", "k_multi_fold_reldiff", "k_multi_decide")
+names = tuple(k for k in names if k in rd and k in wr)   # (single-device stores no longer launch the sweep kernel)
 for k in names:
     kern[k] = {"read": rd[k] * 1024 * factor, "write": wr[k] * 1024}
 if cells:
