@@ -243,7 +243,7 @@ def hbm_traffic(workload):
     return None, None, None
 
 
-def live_hbm_traffic(workload, full, cfg, timeout_s=150):
+def live_hbm_traffic(workload, full, cfg, timeout_s=90):
     """HBM bytes of one E/M pass measured IN THIS RUN, on this box: the PMC passes of MI355X_MICROARCH.md's recipe --
     rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and the FETCH_SIZE calibration stream, each its own pass with
     --kernel-trace only -- over a child process that runs the same pass on the same store (scripts/pass_time.py; the
