@@ -456,8 +456,9 @@ def main():
     # the authors' recommended --model-coverage) and long-read score gaps (uniform on [0, 0.05 best], best up to 20 000:
     # ~520 distinct weights -> 16-bit indices).  `frac` of each against its own algorithmic bytes.
     if rank == 0 and world == 1 and not args.no_f32_compare:
-        def timed(label, rp, ti, pp, cov, **kw):
+        def timed(label, rp, ti, pp, cov, batched=False, **kw):
             try:
+                bp = None
                 with DeviceStore(rp, ti, pp, cov, cfg["n_txps"], device=local_rank, **kw) as o:
                     o.time_em_iters(5)
                     pk = min(o.time_m_step(50) for _ in range(3))   # (three runs of 50 launches: the side stores are timed once, cold)
@@ -465,9 +466,15 @@ def main():
                     _h, ab = o.bytes()
                     nd = o.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
                     nrem = o.info(_lib.OEM_INFO_REMOTE_ALIGNMENTS)
+                    if batched:   # one batched bootstrap pass (4 replicates) over the same store
+                        o.time_bootstrap_passes(5)
+                        bp = o.time_bootstrap_passes(20)
                 roofline["frac_" + label] = ab / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS
                 roofline[label] = dict(kernel_avg_ms=pk, device_ms_per_step=pit, algorithmic_bytes_per_launch=ab,
                                        weight_coding=coding_of(nd), weight_dict_entries=nd, remote_alignments=nrem)
+                if bp:
+                    roofline[label].update(batched_pass_ms=bp[0], replicates_per_batched_pass=bp[1],
+                                           us_per_replicate_pass=bp[0] / bp[1] * 1e3)
             except Exception as e:  # pragma: no cover
                 roofline[label] = dict(error=repr(e))
         if n_dict:
@@ -489,7 +496,7 @@ def main():
             # co-mapping renumbering at store creation would produce (not built: this prices it).
             for far in ("paralog", "paralog_adjacent"):
                 pf = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=threads, far=far)
-                timed(far, pf.row_ptr, pf.tid, pf.as_prob, None)
+                timed(far, pf.row_ptr, pf.tid, pf.as_prob, None, batched=True)
                 del pf
 
     # EM to convergence with the reference's defaults (max_iter 1000, thresh 1e-3), both gates

@@ -413,6 +413,7 @@ static int create_store_layout(const uint64_t *row_ptr, const uint32_t *tid, con
     // reads per tile: small stores are cut finer (oem_layout.h); per-cell batches are large by construction
     uint32_t tile_rows = (uint32_t)knob("OEM_TILE_ROWS", relabel || (opts && opts->problem_size) ? kTileRows : tile_rows_for(n_reads));
     tile_rows = tile_rows < 64u ? 64u : tile_rows > kTileRows ? kTileRows : (tile_rows & ~63u);
+    s->tiled.tile_rows = tile_rows;
     // host copy of the relabelled transcript ids, only for the host builder
     bool relabelled_on_device = false;
     std::vector<uint32_t> vt;

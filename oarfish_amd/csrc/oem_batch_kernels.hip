@@ -80,6 +80,19 @@ constexpr int kFoldThreadsB = 1024;
 // pass; here 1 -> 2 | 4 copies took 6 % off the batched pass, profiles/r04_notes.md.)
 constexpr uint32_t kPoolE = 5888; // 46 KiB: theta + counts 46 + denominators 32 = 78 KiB per workgroup
 constexpr uint32_t kMaxCopyShiftE = 3;
+// Three workgroups per CU (test-only library, OEM_TILE_E_HALF=1 on a store cut into tiles of <= 512 reads,
+// OEM_TILE_ROWS=512): half the denominators, two register-resident records per thread, one slice per wavefront: theta +
+// counts 36 + denominators 16 = 52 KiB, 70 VGPRs.  Measured at C3 (profiles/r05_notes.md): the batched pass is 5 %
+// SLOWER than two workgroups on tiles of 1024 reads -- a tile's window (load, clear, flush) costs the same for half the
+// reads.  Not shipped.
+constexpr uint32_t kRowsHalfE = 512;
+constexpr uint32_t kPoolHalfE = 4608;
+static_assert(kPoolHalfE >= 2 * kWin * kEB, "theta and one copy of the widest window must fit");
+template <uint32_t kRows> struct TileShapeE {
+    static constexpr uint32_t pool = kRows == kTileRows ? kPoolE : kPoolHalfE;
+    static constexpr int rem = kRows == kTileRows ? kRemE : 2;
+    static constexpr int min_waves = kRows == kTileRows ? 4 : 6;
+};
 static_assert(kPoolE >= 2 * kWin * kEB, "theta and one copy of the widest window must fit");
 static_assert(kB % kEB == 0 && kE >= 1, "kBatch must be a multiple of the epoch width");
 static_assert((kB & (kB - 1)) == 0 && kB <= 16, "row multiplicities are packed kB bytes per read");
@@ -101,6 +114,11 @@ __device__ __forceinline__ double *lds_at_b(double *base, uint32_t byte_off)
 // code's spare bits (bits 0..2 and 12..15: oem_layout_dict.hip, read by k_em_tile); this kernel reads the f32 weight
 // stream and only has to look past them (the batched kernel serves narrow-window stores: offsets are bits 3..11).
 __device__ __forceinline__ uint32_t code_off_b(uint32_t half) { return half & 0x0ff8u; }
+// kFused (a store of <= 128 distinct weights, as_prob alone): no weight stream, the weight of a local alignment is the
+// table entry its code's spare bits name (entry 0 = 0.0: padding needs no masking), the table sits in LDS; a remote
+// record's weight is the entry its index byte names (DeviceTiled::r_wi).  The same f32 values as the stream.
+constexpr uint32_t kDictE = 128;
+__device__ __forceinline__ uint32_t code_widx_b(uint32_t half) { return (half & 7u) | ((half >> 9) & 0x78u); }
 
 template <typename WT>
 struct SliceRegsB {
@@ -114,7 +132,7 @@ __device__ __forceinline__ T ld_stream_b(const T *p)
     return kNT ? __builtin_nontemporal_load(p) : *p; // see ld_stream in oem_tile_kernels.hip
 }
 
-template <bool kNT, typename WT>
+template <bool kNT, typename WT, bool kFused = false>
 __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__restrict__ wbase,
                                              const uint32_t *__restrict__ cbase, uint32_t lane,
                                              uint32_t width)
@@ -122,8 +140,10 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__rest
 #pragma unroll
     for (int g = 0; g < kBCh / 2; ++g) {
         if ((uint32_t)(2 * g) < width) {
-            r.w[2 * g] = ld_stream_b<kNT>(&wbase[(2 * g) * 64 + lane]);
-            r.w[2 * g + 1] = ld_stream_b<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            if (!kFused) {
+                r.w[2 * g] = ld_stream_b<kNT>(&wbase[(2 * g) * 64 + lane]);
+                r.w[2 * g + 1] = ld_stream_b<kNT>(&wbase[(2 * g + 1) * 64 + lane]);
+            }
             r.c[g] = ld_stream_b<kNT>(&cbase[g * 64 + lane]);
         } else {
             r.w[2 * g] = (WT)0;
@@ -140,17 +160,24 @@ __device__ __forceinline__ void load_slice_b(SliceRegsB<WT> &r, const WT *__rest
 // time that is two synchronous loads per alignment (the widest slice of a tile has ~8 of them, and the
 // wavefront that owns it holds up the tile's barriers); four at a time it is one round trip per four.  Rows
 // past the slice's width are clamped to its last row and carry no weight.
-template <typename WT>
+template <typename WT, bool kFused>
 __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const uint32_t *__restrict__ cbase, uint32_t lane,
-                                           uint32_t i0 /* even */, uint32_t width, WT wv[4], uint32_t off[4])
+                                           uint32_t i0 /* even */, uint32_t width, WT wv[4], uint32_t off[4], const float *dict_l)
 {
     const uint32_t lastp = (width - 1) >> 1;
     const uint32_t p0 = i0 >> 1, p1 = p0 + 1 <= lastp ? p0 + 1 : lastp;
     const uint32_t c0 = cbase[p0 * 64 + lane], c1 = cbase[p1 * 64 + lane];
+    if (kFused) {
+        wv[0] = (WT)dict_l[code_widx_b(c0 & 0xffffu)];
+        wv[1] = (WT)dict_l[code_widx_b(c0 >> 16)];
+        wv[2] = (WT)dict_l[code_widx_b(c1 & 0xffffu)];
+        wv[3] = (WT)dict_l[code_widx_b(c1 >> 16)];
+    } else {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const uint32_t i = i0 + m;
-        wv[m] = wbase[(i < width ? i : width - 1) * 64 + lane];
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t i = i0 + m;
+            wv[m] = wbase[(i < width ? i : width - 1) * 64 + lane];
+        }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -167,36 +194,41 @@ __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const u
 // wavefront, see fold_first in oem_tile_kernels.hip; the first set is handed to the NEXT slice's loads as soon
 // as the scatter is done with it (`next_*`).  Alignments beyond the register-resident ones are reloaded four at
 // a time by both passes.
-template <typename WT, bool kNT, bool kHasHi>
+template <typename WT, bool kNT, bool kHasHi, uint32_t kRows, bool kFused>
 __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> &hi, uint32_t width, uint32_t mq,
                                              uint32_t rl, uint32_t lane, const WT *__restrict__ wbase,
                                              const uint32_t *__restrict__ cbase, const double *theta_l, double *cnt_l,
                                              double *den_l, const uint32_t (&rot8)[kEB], uint32_t act_e, bool load_next,
                                              const WT *__restrict__ next_w, const uint32_t *__restrict__ next_c,
-                                             uint32_t next_width, uint32_t exp_mask, uint32_t cs, uint32_t cpy)
+                                             uint32_t next_width, uint32_t exp_mask, uint32_t cs, uint32_t cpy,
+                                             const float *dict_l)
 {
     constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
+    auto wt = [&](const SliceRegsB<WT> &r, int k) -> double {
+        if (kFused) return (double)dict_l[code_widx_b((k & 1) ? r.c[k >> 1] >> 16 : r.c[k >> 1] & 0xffffu)];
+        return (double)r.w[k];
+    };
     // Every use of the slice's registers stays below this point: without the pins the compiler hoists the
     // f32 -> f64 conversions of the weights up to their loads and waits for each pair right behind them.
 #pragma unroll
-    for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(lo.w[k]));
+    for (int k = 0; k < kBCh; ++k) if (!kFused) asm volatile("" : "+v"(lo.w[k]));
 #pragma unroll
     for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(lo.c[k]));
     if (kHasHi) {
 #pragma unroll
-        for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(hi.w[k]));
+        for (int k = 0; k < kBCh; ++k) if (!kFused) asm volatile("" : "+v"(hi.w[k]));
 #pragma unroll
         for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(hi.c[k]));
     }
     double denom[kEB];
 #pragma unroll
-    for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kTileRows + rl];
+    for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kRows + rl];
     // (cost attribution, test-only library: every lane reads a fixed word of its own instead of its window entry)
     auto at = [&](uint32_t off, int j) -> uint32_t { return OEM_EXP_E(8u) ? lane * 8u : off + rot8[j]; };
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
-        const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : (double)lo.w[k];
+        const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : wt(lo, k);
 #pragma unroll
         for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;   // em.rs:111
         if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
@@ -205,7 +237,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
-            const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : (double)hi.w[k];
+            const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : wt(hi, k);
 #pragma unroll
             for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;
             if (k & 1) __builtin_amdgcn_sched_barrier(0);
@@ -214,7 +246,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
     for (uint32_t i0 = kReg; i0 < width; i0 += 4) { // reads with more alignments than the registers hold
         WT wv[4];
         uint32_t off4[4];
-        load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
+        load_over4<WT, kFused>(wbase, cbase, lane, i0, width, wv, off4, dict_l);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const double wk = (double)wv[m];
@@ -228,17 +260,17 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
         const uint32_t b = rot8[j] >> 3;
         const double scale = (double)((mq >> (8 * b)) & 0xffu);
         inv[j] = (((act_e >> b) & 1u) && denom[j] > OEM_EM_DENOM_THRESH) ? scale / denom[j] : 0.0; // em.rs:115
-        den_l[b * kTileRows + rl] = inv[j];
+        den_l[b * kRows + rl] = inv[j];
     }
 #pragma unroll
-    for (int k = 0; k < kBCh; ++k) asm volatile("" : "+v"(lo.w[k]));
+    for (int k = 0; k < kBCh; ++k) if (!kFused) asm volatile("" : "+v"(lo.w[k]));
 #pragma unroll
     for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(lo.c[k]));
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         if ((uint32_t)k < width) { // wave-uniform
             const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
-            const double wk = (double)lo.w[k];
+            const double wk = wt(lo, k);
 #pragma unroll
             for (int j = 0; j < kEB; ++j) {
                 const double v = wk * inv[j]; // (theta is multiplied in when the window is flushed)
@@ -248,13 +280,13 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
         __builtin_amdgcn_sched_barrier(0);
     }
     // the first set is free: the next slice's loads go out under the rest of this fold
-    if (kHasHi && load_next) load_slice_b<kNT, WT>(lo, next_w, next_c, lane, next_width);
+    if (kHasHi && load_next) load_slice_b<kNT, WT, kFused>(lo, next_w, next_c, lane, next_width);
     if (kHasHi && width > (uint32_t)kBCh) {
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             if ((uint32_t)(k + kBCh) < width) { // wave-uniform
                 const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
-                const double wk = (double)hi.w[k];
+                const double wk = wt(hi, k);
 #pragma unroll
                 for (int j = 0; j < kEB; ++j) {
                     const double v = wk * inv[j];
@@ -267,7 +299,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
     for (uint32_t i0 = kReg; i0 < width; i0 += 4) {
         WT wv[4];
         uint32_t off4[4];
-        load_over4<WT>(wbase, cbase, lane, i0, width, wv, off4);
+        load_over4<WT, kFused>(wbase, cbase, lane, i0, width, wv, off4, dict_l);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const double wk = (double)wv[m];
@@ -299,14 +331,15 @@ __device__ __forceinline__ void ld_remote_b(const uint32_t *__restrict__ r_a, co
     }
 }
 
-template <bool kNT, typename WT, bool kPacked>
-__global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
+template <bool kNT, typename WT, bool kPacked, uint32_t kRows, bool kFused>
+__global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k_em_tile_e(
     const TileDesc *__restrict__ tiles, const uint32_t *__restrict__ codes,
     const WT *__restrict__ w, const uint32_t *__restrict__ r_a, const WT *__restrict__ r_w,
     const uint16_t *__restrict__ r_row, const uint32_t *__restrict__ sd, uint32_t problem_size,
     double *__restrict__ queue /* [n_remote][kB]: w * c / denom of every remote alignment, the slots side by side */,
     const double *__restrict__ theta /* [T][kB] */, double *__restrict__ cnt /* [T][kB] */,
-    const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */)
+    const BatchState *__restrict__ st, const uint8_t *__restrict__ row_w /* [rows][kB], tile order */,
+    const float *__restrict__ dict, const uint8_t *__restrict__ r_wi /* kFused: the weight table, the records' indices */)
 {
     uint32_t act = 0; // slots that take part in this pass (RUNNING or FINAL)
     uint32_t fin = 0; // slots on their final pass: theta < 1e-5 reads as 0 (em.rs:238-242)
@@ -324,11 +357,15 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     constexpr uint32_t exp_mask = 0u;
 #endif
 
-    __shared__ double pool_l[kPoolE]; // theta window [win_len][kEB], then the count copies [win_len][copies][kEB]
-    __shared__ double den_l[kEB * kTileRows];
+    constexpr uint32_t kPool = TileShapeE<kRows>::pool;
+    constexpr int kRem = TileShapeE<kRows>::rem; // remote alignments per thread kept in registers
+    __shared__ double pool_l[kPool]; // theta window [win_len][kEB], then the count copies [win_len][copies][kEB]
+    __shared__ double den_l[kEB * kRows];
+    __shared__ float dict_l[kFused ? kDictE : 1];
 
     constexpr uint32_t kWaves = kTileThreadsE / 64;
-    constexpr uint32_t kPerWave = kTileSlices / kWaves;
+    constexpr uint32_t kSlices = kRows / 64;
+    constexpr uint32_t kPerWave = kSlices / kWaves;
     const uint32_t tx = threadIdx.x;
     const uint32_t lane = tx & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tx >> 6);
@@ -344,7 +381,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
     {
         uint32_t accw = td.w_base, accc = td.c_base;
 #pragma unroll
-        for (uint32_t i = 0; i < kTileSlices; ++i) {
+        for (uint32_t i = 0; i < kSlices; ++i) {
             const uint32_t wi = td.width[i];
             if (i == slice_of(i / kWaves)) {
                 woff[i / kWaves] = accw;
@@ -370,22 +407,27 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
             tw0[u] = theta[((size_t)td.lo + ic / kEB) * kB + (ic % kEB)];
         }
     }
+    float dict_v = 0.f; // (the weight table, an entry per thread: on its way with the window)
+    if (kFused && tx < kDictE) dict_v = dict[tx];
     // One epoch (kBatch = 4, what ships): the second register set first holds alignments 8..15 of the wavefront's
     // first -- widest -- slice, and its second slice is loaded into the first set half way through that fold
     // (fold_slice_e).  Builds with several epochs keep both slices resident over all of them.
+    // (tiles of <= 512 reads: one slice per wavefront, alignments 8..15 in the second set, nothing to hand over)
     constexpr bool kHandOver = kE == 1 && kPerWave == 2;
-    SliceRegsB<WT> R[kPerWave];
-    load_slice_b<kNT, WT>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
-    if (kHandOver) {
-        load_slice_b<kNT, WT>(R[1], w + ((size_t)woff[0] + kBCh) * 64, codes + ((size_t)coff[0] + kBCh / 2) * 64, lane,
+    constexpr bool kHiOnly = kE == 1 && kPerWave == 1;
+    SliceRegsB<WT> R[kPerWave < 2 ? 2 : kPerWave];
+    load_slice_b<kNT, WT, kFused>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+    if (kHandOver || kHiOnly) {
+        load_slice_b<kNT, WT, kFused>(R[1], w + ((size_t)woff[0] + kBCh) * 64, codes + ((size_t)coff[0] + kBCh / 2) * 64, lane,
                               wid[0] > (uint32_t)kBCh ? wid[0] - kBCh : 0u);
     } else {
 #pragma unroll
         for (uint32_t q = 1; q < kPerWave; ++q)
-            load_slice_b<kNT, WT>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+            load_slice_b<kNT, WT, kFused>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
     }
-    uint32_t rt[kRemE], rrow[kRemE], rslot[kRemE];
-    WT rw[kRemE];
+    uint32_t rt[kRem], rrow[kRem], rslot[kRem];
+    WT rw[kRem];
+    uint32_t ri[kRem];
     const uint32_t tid_base = td.problem * problem_size;
     const uint32_t *sd_t = sd + td.sd_begin - td.b_min; // slot of record i = sd_t[bucket of its transcript] + i
     if (td.remote_cnt) { // wave-uniform
@@ -393,36 +435,41 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // issue back to back (a load per branch is a round trip each)
         const uint32_t last = td.remote_cnt - 1;
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k) {
+        for (int k = 0; k < kRem; ++k) {
             const uint32_t i = tx + k * kTileThreadsE;
             const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
             ld_remote_b<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
-            rw[k] = ld_stream_b<kNT>(&r_w[o]);
+            if (kFused) ri[k] = ld_stream_b<kNT>(&r_wi[o]);
+            else rw[k] = ld_stream_b<kNT>(&r_w[o]);
+        }
+        if (kFused) { // (the table is a few cache lines: a second, short round trip)
+#pragma unroll
+            for (int k = 0; k < kRem; ++k) rw[k] = (WT)dict[ri[k]];
         }
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k)
+        for (int k = 0; k < kRem; ++k)
             if (tx + k * kTileThreadsE >= td.remote_cnt) rw[k] = (WT)0;
     } else {
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
+        for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
     }
 #pragma unroll
-    for (int k = 0; k < kRemE; ++k) rslot[k] = 0;
+    for (int k = 0; k < kRem; ++k) rslot[k] = 0;
     {   // branch-free and back to back (a lookup per branch is a dependent round trip each); a thread without a
         // record reads the tile's first table word (or the table's slack word when the tile has no records)
-        uint32_t sdv[kRemE];
+        uint32_t sdv[kRem];
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k)
+        for (int k = 0; k < kRem; ++k)
             sdv[k] = sd_t[tx + k * kTileThreadsE < td.remote_cnt ? rt[k] >> kBucketShift : td.b_min];
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k) rslot[k] = sdv[k] + tx + k * kTileThreadsE;
+        for (int k = 0; k < kRem; ++k) rslot[k] = sdv[k] + tx + k * kTileThreadsE;
     }
     // slot of this lane at step j of an epoch: (j + lane) mod kEB
     uint32_t rot8[kEB]; // byte offset of that slot inside a [c][b] window entry
 #pragma unroll
     for (int j = 0; j < kEB; ++j) rot8[j] = ((j + lane) & (kEB - 1)) * 8u;
     uint32_t cs = 0; // copies of the count window = 1 << cs (wave-uniform), this lane's at byte cpy of an entry
-    while (cs < kMaxCopyShiftE && td.win_len * kEB * (1u + (2u << cs)) <= kPoolE) ++cs;
+    while (cs < kMaxCopyShiftE && td.win_len * kEB * (1u + (2u << cs)) <= kPool) ++cs;
     double *const theta_l = pool_l;
     double *const cnt_l = pool_l + td.win_len * kEB;
     const uint32_t cpy = ((lane >> 2) & ((1u << cs) - 1u)) * (kEB * 8u);
@@ -448,24 +495,25 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote
         // denominators are never read (no LDS atomics for them) and its c / denom is 0, so its queue entries
         // are written as zeros with the 32-byte piece they share with the other slots.
-        uint32_t rmult[kRemE]; // (loaded branch-free and back to back; a thread without a record discards its word)
+        uint32_t rmult[kRem]; // (loaded branch-free and back to back; a thread without a record discards its word)
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k)
+        for (int k = 0; k < kRem; ++k)
             rmult[k] = *reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rrow[k]) * kB + eoff);
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k)
+        for (int k = 0; k < kRem; ++k)
             if (tx + k * kTileThreadsE >= td.remote_cnt) rmult[k] = 0u;
         // remote alignments: theta[t][b] of the epoch's four slots is one 32-byte piece.  The gathers go out here and
         // are not looked at before phase A: the theta window is written and the windows are cleared while they are
         // in flight.  (Measured and dropped, profiles/r04_notes.md: the first slice's local denominators summed in
         // that shadow too, and dead (read, slot) pairs reading a conflict-free word of their own: +1 % and +2 %.)
-        double rx[kRemE][kEB];
+        double rx[kRem][kEB];
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k) {
+        for (int k = 0; k < kRem; ++k) {
             const double *tp = theta + (size_t)rt[k] * kB + eoff;
 #pragma unroll
             for (int b = 0; b < kEB; ++b) rx[k][b] = OEM_EXP_E(16u) ? 1.0 : tp[b];
         }
+        if (kFused && tx < kDictE) dict_l[tx] = dict_v;
         if (kE == 1) {
 #pragma unroll
             for (uint32_t u = 0; u < kPerT; ++u) {
@@ -479,7 +527,7 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
         for (uint32_t i = tx; i < ((td.win_len * kEB) << cs); i += kTileThreadsE) cnt_l[i] = 0.0;
         for (uint32_t i = tx; i < td.n_slices * 64; i += kTileThreadsE) {
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) den_l[b * kTileRows + i] = 0.0;
+            for (int b = 0; b < kEB; ++b) den_l[b * kRows + i] = 0.0;
         }
         OEM_PROBE_E(2);
         __syncthreads();
@@ -487,40 +535,47 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 
         // ---- remote phase A: denominators ------------------------------------------------
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k)
+        for (int k = 0; k < kRem; ++k)
             if (rmult[k]) {
                 const double wv = (double)rw[k];
 #pragma unroll
                 for (int b = 0; b < kEB; ++b)
-                    if (((rmult[k] >> (8 * b)) & 0xffu) && !OEM_EXP_E(2u)) lds_add(&den_l[b * kTileRows + rrow[k]], th(rx[k][b], b) * wv);
+                    if (((rmult[k] >> (8 * b)) & 0xffu) && !OEM_EXP_E(2u)) lds_add(&den_l[b * kRows + rrow[k]], th(rx[k][b], b) * wv);
             }
-        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // beyond the register-resident records
+        for (uint32_t i = tx + kRem * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) { // beyond the register-resident records
             const uint32_t o = td.remote_begin + i;
             uint32_t t, row;
             ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
             const double *tp = theta + (size_t)t * kB + eoff;
-            const double wv = (double)r_w[o];
+            const double wv = kFused ? (double)dict[r_wi[o]] : (double)r_w[o];
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) lds_add(&den_l[b * kTileRows + row], th(tp[b], b) * wv);
+            for (int b = 0; b < kEB; ++b) lds_add(&den_l[b * kRows + row], th(tp[b], b) * wv);
         }
         OEM_PROBE_E(4);
         __syncthreads();
         OEM_PROBE_E(5);
 
         // ---- local alignments: one read per lane, slots in rotated order ---------------------
-        if (kHandOver) {
-            const uint32_t s0 = slice_of(0), s1 = slice_of(1);
+        if (kHiOnly) {
+            if (wave < td.n_slices)
+                fold_slice_e<WT, kNT, true, kRows, kFused>(R[0], R[1], wid[0], mult[0], wave * 64 + lane, lane, w + (size_t)woff[0] * 64,
+                                                   codes + (size_t)coff[0] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
+                                                   nullptr, nullptr, 0u, exp_mask, cs, cpy, dict_l);
+            OEM_PROBE_E(6);
+            OEM_PROBE_E(7);
+        } else if (kHandOver) {
+            const uint32_t s0 = slice_of(0), s1 = slice_of(kPerWave - 1);
             if (s0 < td.n_slices)
-                fold_slice_e<WT, kNT, true>(R[0], R[1], wid[0], mult[0], s0 * 64 + lane, lane, w + (size_t)woff[0] * 64,
+                fold_slice_e<WT, kNT, true, kRows, kFused>(R[0], R[1], wid[0], mult[0], s0 * 64 + lane, lane, w + (size_t)woff[0] * 64,
                                             codes + (size_t)coff[0] * 64, theta_l, cnt_l, den_l, rot8, act_e, true,
-                                            w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, wid[1], exp_mask, cs, cpy);
+                                            w + (size_t)woff[kPerWave - 1] * 64, codes + (size_t)coff[kPerWave - 1] * 64, wid[kPerWave - 1], exp_mask, cs, cpy, dict_l);
             else
-                load_slice_b<kNT, WT>(R[0], w + (size_t)woff[1] * 64, codes + (size_t)coff[1] * 64, lane, wid[1]);
+                load_slice_b<kNT, WT, kFused>(R[0], w + (size_t)woff[kPerWave - 1] * 64, codes + (size_t)coff[kPerWave - 1] * 64, lane, wid[kPerWave - 1]);
             OEM_PROBE_E(6);
             if (s1 < td.n_slices)
-                fold_slice_e<WT, kNT, false>(R[0], R[0], wid[1], mult[1], s1 * 64 + lane, lane, w + (size_t)woff[1] * 64,
-                                             codes + (size_t)coff[1] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
-                                             nullptr, nullptr, 0u, exp_mask, cs, cpy);
+                fold_slice_e<WT, kNT, false, kRows, kFused>(R[0], R[0], wid[kPerWave - 1], mult[kPerWave - 1], s1 * 64 + lane, lane, w + (size_t)woff[kPerWave - 1] * 64,
+                                             codes + (size_t)coff[kPerWave - 1] * 64, theta_l, cnt_l, den_l, rot8, act_e, false,
+                                             nullptr, nullptr, 0u, exp_mask, cs, cpy, dict_l);
             OEM_PROBE_E(7);
         } else {
 #pragma unroll 1
@@ -542,9 +597,9 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 #pragma unroll
                         for (int k = 0; k < kBCh / 2; ++k) cur.c[k] = R[qq].c[k];
                     }
-                fold_slice_e<WT, kNT, false>(cur, cur, width, mq, s * 64 + lane, lane, w + (size_t)wo * 64,
+                fold_slice_e<WT, kNT, false, kRows, kFused>(cur, cur, width, mq, s * 64 + lane, lane, w + (size_t)wo * 64,
                                              codes + (size_t)co * 64, theta_l, cnt_l, den_l, rot8, act_e, false, nullptr,
-                                             nullptr, 0u, exp_mask, cs, cpy);
+                                             nullptr, 0u, exp_mask, cs, cpy, dict_l);
             }
         }
         __syncthreads();
@@ -552,25 +607,25 @@ __global__ __launch_bounds__(kTileThreadsE, 4) void k_em_tile_e(
 
         // ---- remote phase B: queue[record][.] <- w * (c_ib / denom_ib), the epoch's slots as one 32-byte piece ----
 #pragma unroll
-        for (int k = 0; k < kRemE; ++k) {
+        for (int k = 0; k < kRem; ++k) {
             if (tx + k * kTileThreadsE < td.remote_cnt && !OEM_EXP_E(1u)) {
                 double *qp = queue + (size_t)rslot[k] * kB + eoff;
                 const double wv = (double)rw[k];
                 double qv[kEB];
 #pragma unroll
-                for (int b = 0; b < kEB; ++b) qv[b] = wv * den_l[b * kTileRows + rrow[k]];
+                for (int b = 0; b < kEB; ++b) qv[b] = wv * den_l[b * kRows + rrow[k]];
 #pragma unroll
                 for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(qv[b], &qp[b]);
             }
         }
-        for (uint32_t i = tx + kRemE * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
+        for (uint32_t i = tx + kRem * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {
             const uint32_t o = td.remote_begin + i;
             uint32_t t, row;
             ld_remote_b<kPacked, false>(r_a, r_row, o, tid_base, t, row);
             double *qp = queue + (size_t)(sd_t[t >> kBucketShift] + i) * kB + eoff;
-            const double wv = (double)r_w[o];
+            const double wv = kFused ? (double)dict[r_wi[o]] : (double)r_w[o];
 #pragma unroll
-            for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(wv * den_l[b * kTileRows + row], &qp[b]);
+            for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(wv * den_l[b * kRows + row], &qp[b]);
         }
         // ---- flush the epoch's window: [c][b] -> cnt[lo + c][eoff + b], theta multiplied in here --------
         for (uint32_t i = tx; i < td.win_len * kEB; i += kTileThreadsE) {
@@ -841,10 +896,28 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     const uint64_t wsz = f64w ? 8 : 4;
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
+#ifdef OEM_TESTING // (three workgroups per CU on tiles of <= 512 reads: measured slower, kept for the measurement)
+    const bool half = t.tile_rows <= kRowsHalfE && knob("OEM_TILE_E_HALF", 0) != 0;
+#endif
+    const bool fused = !f64w && t.dict_fused && t.dict && t.r_wi && t.dict_n <= kDictE; // (no weight stream: see kFused)
+#define OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, FUSED)                                                            \
+    hipLaunchKernelGGL((k_em_tile_e<NT, WT, PK, ROWS, FUSED>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream,      \
+                       t.tiles, t.codes, (const WT *)W, PK ? t.r_pk : t.r_tid, (const WT *)RW, t.r_row, t.sd,            \
+                       t.problem_size, bb.queue, bb.theta, bb.cnt, bb.state, bb.row_w, t.dict, t.r_wi)
+#define OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, ROWS)                                                                   \
+    do {                                                                                                              \
+        if (sizeof(WT) == 4 && fused) OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, (sizeof(WT) == 4));                  \
+        else OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, false);                                                      \
+    } while (0)
+#ifdef OEM_TESTING
 #define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK)                                                                         \
-    hipLaunchKernelGGL((k_em_tile_e<NT, WT, PK>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream, t.tiles, t.codes, \
-                       (const WT *)W, PK ? t.r_pk : t.r_tid, (const WT *)RW, t.r_row, t.sd, t.problem_size, bb.queue,    \
-                       bb.theta, bb.cnt, bb.state, bb.row_w)
+    do {                                                                                                              \
+        if (half) OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kRowsHalfE);                                                  \
+        else OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kTileRows);                                                        \
+    } while (0)
+#else
+#define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK) OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kTileRows)
+#endif
 #define OEM_LAUNCH_TILE_E(NT, WT, W, RW)                                                                              \
     do {                                                                                                              \
         if (t.packed) OEM_LAUNCH_TILE_E2(NT, WT, W, RW, true);                                                        \
@@ -857,6 +930,8 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         if (nt) OEM_LAUNCH_TILE_E(true, float, t.w32, t.r_w32);
         else OEM_LAUNCH_TILE_E(false, float, t.w32, t.r_w32);
     }
+#undef OEM_LAUNCH_TILE_E4
+#undef OEM_LAUNCH_TILE_E3
 #undef OEM_LAUNCH_TILE_E2
 #undef OEM_LAUNCH_TILE_E
     OEM_HIP(hipGetLastError());

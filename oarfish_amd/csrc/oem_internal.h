@@ -99,6 +99,7 @@ struct DeviceTiled {
     uint32_t n_tiles = 0;
     uint32_t n_buckets = 0;
     uint32_t win_cap = kWin; // kWin or kWinWide (sparse stores)
+    uint32_t tile_rows = kTileRows; // reads per tile at most (<= 512: the batched tile kernel runs three per CU)
     uint64_t n_rows = 0;    // non-empty reads == length of perm
     uint64_t n_local = 0;
     uint64_t n_remote = 0;

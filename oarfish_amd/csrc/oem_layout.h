@@ -68,7 +68,10 @@ constexpr uint32_t kQueueSlack = kPipeMaxGrid * 4;
 // the remote round trips), so from 500 k reads on -- where the full tiles already cover the chip -- finer tiles
 // only LOSE: 1 M reads 36.3 -> 39.5 -> 46.3 us at 512 / 256 reads per tile, 10 M reads 168 -> 213 -> 321 us
 // (scripts/tile_rows_exp.py, profiles/r04_notes.md).
-inline uint32_t tile_rows_for(uint64_t n_reads) { return n_reads <= (1ull << 18) ? 256u : kTileRows; }
+#ifndef OEM_TILE_ROWS_LARGE
+#define OEM_TILE_ROWS_LARGE kTileRows // (A/B builds: -DOEM_TILE_ROWS_LARGE=512)
+#endif
+inline uint32_t tile_rows_for(uint64_t n_reads) { return n_reads <= (1ull << 18) ? 256u : OEM_TILE_ROWS_LARGE; }
 
 // Everything a workgroup needs to know about its tile, fetched with one scalar
 // load: with the slice widths in hand every wavefront derives the addresses of

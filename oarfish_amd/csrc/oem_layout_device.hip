@@ -681,6 +681,7 @@ int build_tiled_layout_device(oem_store *s, uint32_t problem_size, uint32_t win_
         hipFree(t.r_w32); hipFree(t.r_w64); hipFree(t.r_row); hipFree(t.r_slot); hipFree(t.q_dst);
         hipFree(t.bucket_base); hipFree(t.queue); hipFree(t.row_w_perm);
         t = DeviceTiled();
+        t.tile_rows = tile_rows;
     }
     return rc;
 }
