@@ -15,7 +15,8 @@ if cov:
     st = synth.make_store(10_000_000, 200_000, 8.0, coverage=True, threads=min(32, os.cpu_count() or 8))
 else:
     st = synth.make_config(wl)
-with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob if cov else None, st.n_txps) as d:
+wc = int(os.environ.get("OEM_WEIGHT_CODING", "0"))   # 1: the f32 weight stream (oem_store_opts.weight_coding)
+with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob if cov else None, st.n_txps, weight_coding=wc) as d:
     ms, slots, nbytes = d.time_bootstrap_passes(n)
     print(f"batched pass: {ms:.4f} ms for {slots} replicates = {ms / slots * 1e3:.1f} us per replicate-pass; "
           f"{nbytes / ms / 1e6:.0f} GB/s algorithmic")
