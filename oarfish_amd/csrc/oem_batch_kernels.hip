@@ -64,6 +64,12 @@ __device__ unsigned int g_tile_e_exp = 0;
 #define OEM_EXP_E(bit) false
 #endif
 
+#ifndef OEM_E_RD_GROUP
+#define OEM_E_RD_GROUP 2 // alignments whose LDS reads (x 4 slots) are in flight together in pass 1 of fold_slice_e
+#endif
+#ifndef OEM_E_WR_GROUP
+#define OEM_E_WR_GROUP 1 // alignments whose LDS atomics are issued together in pass 2
+#endif
 constexpr int kB = kBatch;
 constexpr int kEB = 4;             // slots per epoch
 constexpr int kE = kB / kEB;       // epochs per pass
@@ -231,7 +237,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
         const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : wt(lo, k);
 #pragma unroll
         for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;   // em.rs:111
-        if (k & 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
+        if ((k & (OEM_E_RD_GROUP - 1)) == OEM_E_RD_GROUP - 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
     }
     if (kHasHi && width > (uint32_t)kBCh) { // wave-uniform
 #pragma unroll
@@ -240,7 +246,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
             const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : wt(hi, k);
 #pragma unroll
             for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;
-            if (k & 1) __builtin_amdgcn_sched_barrier(0);
+            if ((k & (OEM_E_RD_GROUP - 1)) == OEM_E_RD_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
     for (uint32_t i0 = kReg; i0 < width; i0 += 4) { // reads with more alignments than the registers hold
@@ -277,7 +283,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
                 if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, (off << cs) + cpy + rot8[j]), v);    // em.rs:128-129
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if ((k & (OEM_E_WR_GROUP - 1)) == OEM_E_WR_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
     // the first set is free: the next slice's loads go out under the rest of this fold
     if (kHasHi && load_next) load_slice_b<kNT, WT, kFused>(lo, next_w, next_c, lane, next_width);
@@ -293,7 +299,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
                     if (v != 0.0 && !OEM_EXP_E(4u)) lds_add(lds_at_b(cnt_l, (off << cs) + cpy + rot8[j]), v);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if ((k & (OEM_E_WR_GROUP - 1)) == OEM_E_WR_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
     for (uint32_t i0 = kReg; i0 < width; i0 += 4) {

@@ -28,6 +28,18 @@
 // into LDS once per workgroup, not per tile.
 #include "oem_internal.h"
 
+#ifndef OEM_TESTING
+// The product library carries no pipeline kernels: measured slower than k_em_tile (below), they exist for the tests and
+// the measurement scripts.
+namespace oem {
+bool tile_pipeline_applies(const oem_store *, const BatchState *) { return false; }
+int launch_tile_pipeline(oem_store *, const double *, double *, const EmState *, const uint32_t *, bool)
+{
+    return fail(OEM_ERR_STATE, "the pipelined tile walk is part of the test-only library");
+}
+} // namespace oem
+#else
+
 #define OEM_PROBE(i) do { } while (0)
 #include "oem_tile_common.h"
 
@@ -677,3 +689,4 @@ int launch_tile_pipeline(oem_store *s, const double *theta, double *cnt, const E
 }
 
 } // namespace oem
+#endif // OEM_TESTING
