@@ -64,6 +64,9 @@ __device__ unsigned int g_tile_e_exp = 0;
 #define OEM_EXP_E(bit) false
 #endif
 
+#ifndef OEM_E_MULT_NT
+#define OEM_E_MULT_NT 0 // the reads' multiplicity words streamed non-temporally (A/B)
+#endif
 #ifndef OEM_E_RD_GROUP
 #define OEM_E_RD_GROUP 2 // alignments whose LDS reads (x 4 slots) are in flight together in pass 1 of fold_slice_e
 #endif
@@ -422,15 +425,19 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
     constexpr bool kHandOver = kE == 1 && kPerWave == 2;
     constexpr bool kHiOnly = kE == 1 && kPerWave == 1;
     SliceRegsB<WT> R[kPerWave < 2 ? 2 : kPerWave];
-    load_slice_b<kNT, WT, kFused>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
-    if (kHandOver || kHiOnly) {
-        load_slice_b<kNT, WT, kFused>(R[1], w + ((size_t)woff[0] + kBCh) * 64, codes + ((size_t)coff[0] + kBCh / 2) * 64, lane,
-                              wid[0] > (uint32_t)kBCh ? wid[0] - kBCh : 0u);
-    } else {
+    // (requested behind the records: loads return in order, and the records -- left to the caches, OEM_REC_NT -- are what
+    // the theta gathers hang on; the slices stream from memory and are wanted two barriers later)
+    auto load_slices = [&]() {
+        load_slice_b<kNT, WT, kFused>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0]);
+        if (kHandOver || kHiOnly) {
+            load_slice_b<kNT, WT, kFused>(R[1], w + ((size_t)woff[0] + kBCh) * 64, codes + ((size_t)coff[0] + kBCh / 2) * 64, lane,
+                                          wid[0] > (uint32_t)kBCh ? wid[0] - kBCh : 0u);
+        } else {
 #pragma unroll
-        for (uint32_t q = 1; q < kPerWave; ++q)
-            load_slice_b<kNT, WT, kFused>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
-    }
+            for (uint32_t q = 1; q < kPerWave; ++q)
+                load_slice_b<kNT, WT, kFused>(R[q], w + (size_t)woff[q] * 64, codes + (size_t)coff[q] * 64, lane, wid[q]);
+        }
+    };
     uint32_t rt[kRem], rrow[kRem], rslot[kRem];
     WT rw[kRem];
     uint32_t ri[kRem];
@@ -444,10 +451,11 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
         for (int k = 0; k < kRem; ++k) {
             const uint32_t i = tx + k * kTileThreadsE;
             const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-            ld_remote_b<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
-            if (kFused) ri[k] = ld_stream_b<kNT>(&r_wi[o]);
-            else rw[k] = ld_stream_b<kNT>(&r_w[o]);
+            ld_remote_b<kPacked, kNT && OEM_REC_NT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
+            if (kFused) ri[k] = ld_stream_b<kNT && OEM_REC_NT>(&r_wi[o]);
+            else rw[k] = ld_stream_b<kNT && OEM_REC_NT>(&r_w[o]);
         }
+        load_slices();
         if (kFused) { // (the table is a few cache lines: a second, short round trip)
 #pragma unroll
             for (int k = 0; k < kRem; ++k) rw[k] = (WT)dict[ri[k]];
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
         for (int k = 0; k < kRem; ++k)
             if (tx + k * kTileThreadsE >= td.remote_cnt) rw[k] = (WT)0;
     } else {
+        load_slices();
 #pragma unroll
         for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
     }
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
 #pragma unroll
         for (uint32_t q = 0; q < kPerWave; ++q) {
             const uint32_t rl = slice_of(q) * 64 + lane;
-            mult[q] = rl < td.n_rows ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff)) : 0u;
+            mult[q] = rl < td.n_rows ? ld_stream_b<OEM_E_MULT_NT != 0>(reinterpret_cast<const uint32_t *>(row_w + (size_t)(td.row_base + rl) * kB + eoff)) : 0u;
         }
         // multiplicities of the reads of this thread's remote records (4 KB per tile: cache-resident).  A read
         // that a slot's resample did not draw (1/e of them) takes no part in that slot's pass: its remote

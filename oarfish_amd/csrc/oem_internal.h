@@ -138,6 +138,14 @@ struct DeviceTiled {
 // (oem_batch_kernels.hip).  Per-slot loop state, walked on the device:
 // RUNNING -> FINAL (small abundances read as 0, one more pass) -> FINISHED.
 // ---------------------------------------------------------------------------
+// Whether the remote records of a store larger than the Infinity Cache are streamed non-temporally like its slices
+// (1) or left to the caches (0): A/B switch of the tile kernels.
+#ifndef OEM_REC_NT
+#define OEM_REC_NT 0
+#endif
+#ifndef OEM_QUEUE_NT
+#define OEM_QUEUE_NT 1 // k_em_tile writes its queue entries non-temporally (A/B)
+#endif
 #ifndef OEM_KBATCH
 #define OEM_KBATCH 4
 #endif

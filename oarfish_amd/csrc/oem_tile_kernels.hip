@@ -208,9 +208,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
-                ld_remote<kPacked, kNT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
-                if (kRemIdx) ri[k] = ld_stream<kNT>(&r_wi[o]);
-                else rw[k] = ld_stream<kNT>(&r_w[o]);
+                ld_remote<kPacked, kNT && OEM_REC_NT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
+                if (kRemIdx) ri[k] = ld_stream<kNT && OEM_REC_NT>(&r_wi[o]);
+                else rw[k] = ld_stream<kNT && OEM_REC_NT>(&r_w[o]);
             }
             // (the records are requested ahead of the slices: loads return in order, so the gathers that hang on
             // the records go out one round trip after the kernel starts, not behind all the slices' data -- 1 % of
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
     for (int k = 0; k < kRem; ++k) {
         const uint32_t i = tx + k * kTileThreads;
-        if (i < td.remote_cnt && !OEM_EXP(1u)) __builtin_nontemporal_store(rx[k] * den_l[rrow[k]], &queue[rslot[k]]);
+        if (i < td.remote_cnt && !OEM_EXP(1u)) {
+            if (OEM_QUEUE_NT) __builtin_nontemporal_store(rx[k] * den_l[rrow[k]], &queue[rslot[k]]);
+            else queue[rslot[k]] = rx[k] * den_l[rrow[k]];
+        }
     }
     for (uint32_t i = tx + kRem * kTileThreads; i < td.remote_cnt; i += kTileThreads) {
         const uint32_t o = td.remote_begin + i;
