@@ -64,6 +64,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     constexpr uint32_t kCntEntries = (kCopies > 1 && OEM_CNT_ENTRIES) ? OEM_CNT_ENTRIES : kWinT * (uint32_t)kCopies;
     __shared__ double cnt_l[kCntEntries];
     __shared__ double den_l[kTileRows]; // remote part of the denominators, then c_i/denom_i
+#ifdef OEM_LDS_PAD // (A/B: fewer workgroups per CU by LDS)
+    __shared__ double pad_l[OEM_LDS_PAD / 8];
+    pad_l[threadIdx.x * 7 % (OEM_LDS_PAD / 8)] = 1.0;
+    asm volatile("" ::"v"(pad_l[(threadIdx.x * 13 + 5) % (OEM_LDS_PAD / 8)]));
+#endif
 
     OEM_PROBE(0);
 #ifdef OEM_TESTING

@@ -47,3 +47,12 @@ start = (t[:, 0] - t[:, 0].min()) * us
 order = np.argsort(start)
 print("dispatch: first start of tiles #0/#1279/#1280/#2560/#5120/last:",
       [round(float(start[order[min(k, n - 1)]]), 1) for k in (0, 1279, 1280, 2560, 5120, n - 1)])
+# occupancy over the kernel's life: resident workgroups in ten slices of its span, and what the ramp and the tail cost
+end = (t[:, 11] - t[:, 0].min()) * us
+edges = np.linspace(0.0, span, 11)
+occ = [float(np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)) for a, b in zip(edges[:-1], edges[1:])]
+print("resident workgroups by tenth of the span:", [round(o) for o in occ])
+last_start = float(start.max())
+print(f"last tile starts at {last_start:.1f} us of {span:.1f}: the tail after it is {span - last_start:.1f} us "
+      f"({(span - last_start) / span:.1%} of the span) at a mean of "
+      f"{float(np.clip(end - np.maximum(start, last_start), 0, None).sum() / max(span - last_start, 1e-9)):.0f} resident workgroups")
