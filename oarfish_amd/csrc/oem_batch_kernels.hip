@@ -120,14 +120,18 @@ __device__ __forceinline__ double *lds_at_b(double *base, uint32_t byte_off)
 }
 
 // LDS byte offset of a 16-bit window code.  A store with at most 128 distinct weights carries a table index in the
-// code's spare bits (bits 0..2 and 12..15: oem_layout_dict.hip, read by k_em_tile); this kernel reads the f32 weight
+// spare bits of the pair of codes (bits 0..2 and 12..15 of either half: oem_layout_dict.hip, read by k_em_tile); this kernel reads the f32 weight
 // stream and only has to look past them (the batched kernel serves narrow-window stores: offsets are bits 3..11).
 __device__ __forceinline__ uint32_t code_off_b(uint32_t half) { return half & 0x0ff8u; }
 // kFused (a store of <= 128 distinct weights, as_prob alone): no weight stream, the weight of a local alignment is the
 // table entry its code's spare bits name (entry 0 = 0.0: padding needs no masking), the table sits in LDS; a remote
 // record's weight is the entry its index byte names (DeviceTiled::r_wi).  The same f32 values as the stream.
 constexpr uint32_t kDictE = 128;
-__device__ __forceinline__ uint32_t code_widx_b(uint32_t half) { return (half & 7u) | ((half >> 9) & 0x78u); }
+__device__ __forceinline__ uint32_t code_widx_b(uint32_t c, int h) // (see code_widx in oem_tile_common.h)
+{
+    const uint32_t r = h ? ((c >> 26) | (c << 6)) : ((c >> 10) | (c << 22));
+    return (r >> 2) & 0x7fu;
+}
 
 template <typename WT>
 struct SliceRegsB {
@@ -177,10 +181,10 @@ __device__ __forceinline__ void load_over4(const WT *__restrict__ wbase, const u
     const uint32_t p0 = i0 >> 1, p1 = p0 + 1 <= lastp ? p0 + 1 : lastp;
     const uint32_t c0 = cbase[p0 * 64 + lane], c1 = cbase[p1 * 64 + lane];
     if (kFused) {
-        wv[0] = (WT)dict_l[code_widx_b(c0 & 0xffffu)];
-        wv[1] = (WT)dict_l[code_widx_b(c0 >> 16)];
-        wv[2] = (WT)dict_l[code_widx_b(c1 & 0xffffu)];
-        wv[3] = (WT)dict_l[code_widx_b(c1 >> 16)];
+        wv[0] = (WT)dict_l[code_widx_b(c0, 0)];
+        wv[1] = (WT)dict_l[code_widx_b(c0, 1)];
+        wv[2] = (WT)dict_l[code_widx_b(c1, 0)];
+        wv[3] = (WT)dict_l[code_widx_b(c1, 1)];
     } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 {
     constexpr uint32_t kReg = kHasHi ? 2 * kBCh : kBCh; // register-resident alignments
     auto wt = [&](const SliceRegsB<WT> &r, int k) -> double {
-        if (kFused) return (double)dict_l[code_widx_b((k & 1) ? r.c[k >> 1] >> 16 : r.c[k >> 1] & 0xffffu)];
+        if (kFused) return (double)dict_l[code_widx_b(r.c[k >> 1], k & 1)];
         return (double)r.w[k];
     };
     // Every use of the slice's registers stays below this point: without the pins the compiler hoists the

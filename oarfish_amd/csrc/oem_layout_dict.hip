@@ -4,7 +4,8 @@
 // (oarfish_types.rs:1100-1114): alignment scores are integers, so a store holds as many distinct weights as it
 // holds distinct score gaps -- tens to a few hundred, not 80 M.  When there are at most 256 of them the local
 // weights are stored as an index into a table of the distinct f32 values: with up to 128 values FUSED into the
-// spare bits of the alignment's 16-bit window code (bits 0..2 and 12..15: a code is 8 * (transcript - lo) < 4096)
+// spare bits of the word an alignment's 16-bit window code shares with its neighbour's (bits 0..2 and 12..15 of either
+// half: a code is 8 * (transcript - lo) < 4096; k_dict_fuse below says which bits hold what)
 // -- a local alignment is then its two code bytes and nothing else -- with 129..256 as BYTES, four indices per u32
 // in the tiles' SELL layout (1 + 2 bytes per local alignment).  The f32 stream costs 4 + 2.  The table sits in
 // 1 KiB of LDS per workgroup, and the value the kernel multiplies with is bit for bit the f32 the caller handed
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(kDT) void k_dict_encode_remote(const float *__restr
     }
 }
 
-// <= 128 distinct weights: the index goes into the spare bits of the alignment's own window code (bits 0..2 and
-// 12..15 of its 16-bit half; the code is 8 * (transcript - lo) < 4096), no index stream
+// <= 128 distinct weights: the index goes into the spare bits of the pair of window codes an alignment shares a word
+// with (a code is 8 * (transcript - lo) < 4096: bits 0..2 and 12..15 of either half are free): its low four bits into
+// bits 12..15 of its own half, its high three into bits 0..2 of the other half; no index stream
 // kCheckOnly: nothing is written -- the codes are changed in place, so the pass that changes them runs only after
 // this one has found every code and every weight to fit (a store that does not keeps its untouched codes and takes
 // the next coding down)
@@ -222,7 +224,8 @@ __global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ 
         const uint32_t width = td.width[s], pairs = (width + 1u) >> 1;
         for (uint32_t e = threadIdx.x; e < pairs * 64; e += kDT) {
             const uint32_t g = e >> 6, lane = e & 63u;
-            uint32_t word = codes[(size_t)(coff + g) * 64 + lane];
+            const uint32_t word0 = codes[(size_t)(coff + g) * 64 + lane];
+            uint32_t word = word0;
             for (uint32_t m = 0; m < 2; ++m) {
                 const uint32_t j = 2 * g + m;
                 if (j >= width) break;
@@ -234,9 +237,11 @@ __global__ __launch_bounds__(kDT) void k_dict_fuse(const TileDesc *__restrict__ 
                     else b = mid;
                 }
                 if (a >= n_dict || keys[a] != key || a > 127u) { *bad = 1u; a = 0; }
-                const uint32_t half = (word >> (16 * m)) & 0xffffu;
+                const uint32_t half = (word0 >> (16 * m)) & 0xffffu;
                 if (half & 0xf007u) *bad = 1u; // (a code of the narrow window has these bits clear)
-                word |= ((a & 7u) | ((a & 0x78u) << 9)) << (16 * m);
+                // low four bits of the index into the alignment's own half, the high three into the low bits of the
+                // pair's other half (code_widx, oem_tile_common.h: one rotation of the word decodes it)
+                word |= ((a & 15u) << (12 + 16 * m)) | (((a >> 4) & 7u) << (16 * (1 - m)));
             }
             if (!kCheckOnly) codes[(size_t)(coff + g) * 64 + lane] = word;
         }

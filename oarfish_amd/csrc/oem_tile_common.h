@@ -90,8 +90,9 @@ struct SliceRegs {
     uint32_t c[kCh / 2];
 };
 // Weight coding of a store (oem_layout_dict.hip): 0 the f32 / f64 stream; 1 one-byte table indices in their own
-// stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the alignment's 16-bit window code
-// (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so its bits 0..2 and 12..15 are free) --
+// stream (129..256 distinct weights); 2 FUSED: a 7-bit index in the spare bits of the pair of 16-bit window codes an
+// alignment shares a word with (up to 128 distinct weights: a code is 8 * (transcript - lo) < 4096, so bits 0..2 and
+// 12..15 of either half are free; which bits: code_widx below) --
 // no weight stream at all, a local alignment is its two code bytes; 3 WORDS: 16-bit indices, two per u32, stored in
 // the geometry of the window codes (257..1024 distinct weights -- long reads with score gaps in the hundreds).
 constexpr int kWPlain = 0, kWBytes = 1, kWFused = 2, kWWords = 3;
@@ -155,7 +156,15 @@ template <typename WT, int kDict> constexpr int tile_min_waves()
 __device__ __forceinline__ uint32_t code_half(uint32_t c, int h) { return h ? c >> 16 : c & 0xffffu; }
 template <int kDict>
 __device__ __forceinline__ uint32_t code_off(uint32_t half) { return kDict == kWFused ? half & 0x0ff8u : half; } // LDS byte offset
-__device__ __forceinline__ uint32_t code_widx(uint32_t half) { return (half & 7u) | ((half >> 9) & 0x78u); }
+// Table index of half h of a pair of FUSED codes (oem_layout_dict.hip): its low four bits sit in bits 12..15 of the
+// alignment's own half, its high three in bits 0..2 of the OTHER half of the word -- one rotation of the word puts both
+// where the table offset wants them (v_alignbit_b32 + v_and_b32, against four logic operations for two fields of the
+// same half).
+__device__ __forceinline__ uint32_t code_widx(uint32_t c, int h)
+{
+    const uint32_t r = h ? ((c >> 26) | (c << 6)) : ((c >> 10) | (c << 22));
+    return (r >> 2) & 0x7fu;
+}
 // weight of entry k of a register set: coded stores read it from the table in LDS (index 0 = 0.0: padded entries
 // and entries beyond the slice's width need no masking)
 template <int kDict, typename WT, int kCh>
@@ -163,7 +172,7 @@ __device__ __forceinline__ WT slice_w(const SliceRegs<WT, kCh> &r, int k, const 
 {
     if (kDict == kWBytes) return (WT)dict_l[(r.wi[k >> 2] >> (8 * (k & 3))) & 0xffu];
     if (kDict == kWWords) return (WT)dict_l[code_half(r.wi[k >> 1], k & 1)];
-    if (kDict == kWFused) return (WT)dict_l[code_widx(code_half(r.c[k >> 1], k & 1))];
+    if (kDict == kWFused) return (WT)dict_l[code_widx(r.c[k >> 1], k & 1)];
     return r.w[k];
 }
 
@@ -216,7 +225,7 @@ __device__ __forceinline__ void fold_slice(const SliceRegs<WT, kCh> &cur, uint32
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
         if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
-        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
+        if (kDict == kWFused) return (double)dict_l[code_widx(cbase[(j >> 1) * 64 + lane], j & 1)];
         return (double)wbase[j * 64 + lane];
     };
     const uint32_t rl = s * 64 + lane;
@@ -332,7 +341,7 @@ __device__ __forceinline__ void fold_first(SliceRegs<WT, kCh> &lo, const SliceRe
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
         if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
-        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
+        if (kDict == kWFused) return (double)dict_l[code_widx(cbase[(j >> 1) * 64 + lane], j & 1)];
         return (double)wbase[j * 64 + lane];
     };
     const uint32_t rl = s * 64 + lane;

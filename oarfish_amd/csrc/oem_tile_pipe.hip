@@ -220,7 +220,7 @@ __device__ __forceinline__ void fold_slice_b(const SliceRegs<WT, kCh> &lo, const
     auto w_at = [&](uint32_t j) -> double {
         if (kDict == kWBytes) return (double)dict_l[(ibase[(j >> 2) * 64 + lane] >> (8 * (j & 3))) & 0xffu];
         if (kDict == kWWords) return (double)dict_l[code_half(ibase[(j >> 1) * 64 + lane], j & 1)];
-        if (kDict == kWFused) return (double)dict_l[code_widx(code_half(cbase[(j >> 1) * 64 + lane], j & 1))];
+        if (kDict == kWFused) return (double)dict_l[code_widx(cbase[(j >> 1) * 64 + lane], j & 1)];
         return (double)wbase[j * 64 + lane];
     };
     constexpr uint32_t kHeld = kTwo ? 2 * kCh : kCh;
