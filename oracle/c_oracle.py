@@ -135,13 +135,36 @@ def do_em(store: Store, init=None, max_iter=1000, conv_thresh=1e-3, min_iter_gat
     return out, _info(ri)
 
 
+def default_threads() -> int:
+    """Threads for the parallel entry points: the CPUs this process may actually use (its affinity mask, capped by the
+    cgroup's CPU quota -- a GPU box shows 256 CPUs and grants 16), not os.cpu_count(): 256 threads spinning on
+    compare-and-swap adds over 16 CPUs' worth of quota ran the C2 check at 7 iterations/s."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:   # cgroup v2: "quota period" or "max period"
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if len(q) == 2 and q[0] != "max" and float(q[1]) > 0:
+            n = min(n, max(1, int(float(q[0]) / float(q[1]) + 0.5)))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def em_par(store: Store, init=None, max_iter=1000, conv_thresh=1e-3, min_iter_gate=1, nthreads=None):
     """em.rs:320-447."""
     out = np.zeros(store.n_txps, dtype=np.float64)
     ri = _RunInfo()
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.float64)
-    nthreads = nthreads or os.cpu_count() or 1
+    nthreads = nthreads or default_threads()
     rc = lib().oracle_em_par(store.c, _p(init), C.c_uint32(max_iter), C.c_double(conv_thresh),
                              C.c_uint32(min_iter_gate), C.c_int(nthreads), _p(out), C.byref(ri))
     if rc:
@@ -172,7 +195,7 @@ def bootstrap(store: Store, n_boot: int, seed=0, row_w_all=None, init=None, max_
         assert row_w_all.shape == (n_boot, store.n_reads)
     if init is not None:
         init = np.ascontiguousarray(init, dtype=np.float64)
-    nthreads = nthreads or os.cpu_count() or 1
+    nthreads = nthreads or default_threads()
     rc = lib().oracle_bootstrap(store.c, _p(init), C.c_uint32(n_boot), C.c_uint64(seed),
                                 _p(row_w_all), C.c_uint32(max_iter), C.c_double(conv_thresh),
                                 C.c_int(nthreads), _p(out), infos)
