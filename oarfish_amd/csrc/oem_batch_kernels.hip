@@ -233,26 +233,33 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
 #pragma unroll
         for (int k = 0; k < kBCh / 2; ++k) asm volatile("" : "+v"(hi.c[k]));
     }
-    double denom[kEB];
+    // Pass 1 in the slots' natural order: the four slots of a window entry are one 32-byte piece, read as two 16-byte
+    // halves -- two LDS instructions per alignment and no address arithmetic, against four 8-byte reads in the lanes'
+    // rotated slot order with an address each.  The rotation only matters to the atomics of pass 2: c / denom of
+    // the four slots is put into the lane's order once per slice.
+    double dn[kEB];
 #pragma unroll
-    for (int j = 0; j < kEB; ++j) denom[j] = den_l[(rot8[j] >> 3) * kRows + rl];
-    // (cost attribution, test-only library: every lane reads a fixed word of its own instead of its window entry)
-    auto at = [&](uint32_t off, int j) -> uint32_t { return OEM_EXP_E(8u) ? lane * 8u : off + rot8[j]; };
+    for (int b = 0; b < kEB; ++b) dn[b] = den_l[b * kRows + rl];
+    static_assert(kEB == 4, "two 16-byte halves of a [c][4] entry");
+    auto add4 = [&](uint32_t off, double wk) {
+        const char *e = reinterpret_cast<const char *>(theta_l) + (OEM_EXP_E(8u) ? lane * 32u : off);
+        const double2 lo2 = *reinterpret_cast<const double2 *>(e), hi2 = *reinterpret_cast<const double2 *>(e + 16);
+        dn[0] += lo2.x * wk;   // em.rs:111
+        dn[1] += lo2.y * wk;
+        dn[2] += hi2.x * wk;
+        dn[3] += hi2.y * wk;
+    };
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) {
         const uint32_t off = code_off_b((k & 1) ? lo.c[k >> 1] >> 16 : lo.c[k >> 1]) * kEB;
-        const double wk = ((k & 1) && (uint32_t)k >= width) ? 0.0 : wt(lo, k);
-#pragma unroll
-        for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;   // em.rs:111
-        if ((k & (OEM_E_RD_GROUP - 1)) == OEM_E_RD_GROUP - 1) __builtin_amdgcn_sched_barrier(0); // two alignments' LDS reads in flight, not all eight
+        add4(off, ((k & 1) && (uint32_t)k >= width) ? 0.0 : wt(lo, k));
+        if ((k & (OEM_E_RD_GROUP - 1)) == OEM_E_RD_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
     if (kHasHi && width > (uint32_t)kBCh) { // wave-uniform
 #pragma unroll
         for (int k = 0; k < kBCh; ++k) {
             const uint32_t off = code_off_b((k & 1) ? hi.c[k >> 1] >> 16 : hi.c[k >> 1]) * kEB;
-            const double wk = ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : wt(hi, k);
-#pragma unroll
-            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off, j)) * wk;
+            add4(off, ((k & 1) && (uint32_t)(k + kBCh) >= width) ? 0.0 : wt(hi, k));
             if ((k & (OEM_E_RD_GROUP - 1)) == OEM_E_RD_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -261,19 +268,20 @@ __device__ __forceinline__ void fold_slice_e(SliceRegsB<WT> &lo, SliceRegsB<WT> 
         uint32_t off4[4];
         load_over4<WT, kFused>(wbase, cbase, lane, i0, width, wv, off4, dict_l);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const double wk = (double)wv[m];
-#pragma unroll
-            for (int j = 0; j < kEB; ++j) denom[j] += lds_ld_b(theta_l, at(off4[m], j)) * wk;
-        }
+        for (int m = 0; m < 4; ++m) add4(off4[m], (double)wv[m]);
     }
-    double inv[kEB];
+    double inv_n[kEB];
+#pragma unroll
+    for (int b = 0; b < kEB; ++b) {
+        const double scale = (double)((mq >> (8 * b)) & 0xffu);
+        inv_n[b] = (((act_e >> b) & 1u) && dn[b] > OEM_EM_DENOM_THRESH) ? scale / dn[b] : 0.0; // em.rs:115
+        den_l[b * kRows + rl] = inv_n[b];
+    }
+    double inv[kEB]; // inv[j]: of the slot this lane works on at step j, (j + lane) mod 4
 #pragma unroll
     for (int j = 0; j < kEB; ++j) {
         const uint32_t b = rot8[j] >> 3;
-        const double scale = (double)((mq >> (8 * b)) & 0xffu);
-        inv[j] = (((act_e >> b) & 1u) && denom[j] > OEM_EM_DENOM_THRESH) ? scale / denom[j] : 0.0; // em.rs:115
-        den_l[b * kRows + rl] = inv[j];
+        inv[j] = b == 0 ? inv_n[0] : b == 1 ? inv_n[1] : b == 2 ? inv_n[2] : inv_n[3];
     }
 #pragma unroll
     for (int k = 0; k < kBCh; ++k) if (!kFused) asm volatile("" : "+v"(lo.w[k]));
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
 
     constexpr uint32_t kPool = TileShapeE<kRows>::pool;
     constexpr int kRem = TileShapeE<kRows>::rem; // remote alignments per thread kept in registers
-    __shared__ double pool_l[kPool]; // theta window [win_len][kEB], then the count copies [win_len][copies][kEB]
+    __shared__ __attribute__((aligned(16))) double pool_l[kPool]; // theta window [win_len][kEB], then the count copies [win_len][copies][kEB]
     __shared__ double den_l[kEB * kRows];
     __shared__ float dict_l[kFused ? kDictE : 1];
 
