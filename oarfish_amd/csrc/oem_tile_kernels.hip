@@ -28,7 +28,18 @@
         if (g_tile_probe && threadIdx.x == 0) g_tile_probe[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
 #define OEM_EXP(bit) ((exp_mask & (bit)) != 0u) // (exp_mask: g_tile_exp read once per kernel, an SGPR)
+// the kernel cut short behind a phase (2048: at once, 1024: with the descriptor in hand, 128: behind the first barrier,
+// 256: the second, 512: the third -- no queue stores, no flush): what the tiles cost up to there, at the real
+// occupancy; 4096: no slice is requested, 8192: no record (scripts/tile_phase_exp.sh)
+#define OEM_EXIT_AT(bit)                                                \
+    do {                                                                \
+        if (OEM_EXP(bit)) {                                             \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+            return;                                                     \
+        }                                                               \
+    } while (0)
 #else
+#define OEM_EXIT_AT(bit) do { } while (0)
 #define OEM_PROBE(i) do { } while (0)
 #define OEM_EXP(bit) false
 #endif
@@ -76,6 +87,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #else
     constexpr uint32_t exp_mask = 0u;
 #endif
+    OEM_EXIT_AT(2048u); // (an empty workgroup: what dispatching the grid costs)
     // (the descriptor is requested before the run's state is looked at: two scalar loads in flight, not a chain)
     // Per-cell batch: the abundances of ALL cells together (300 MB for 625 cells) fit no cache, those of the cells
     // one XCD is working on do (a cell's 60 k transcripts are 480 KB of its 4 MiB L2) -- if the XCD works on few
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     };
 
     OEM_PROBE(1); // descriptor in hand, slice addresses derived
+    OEM_EXIT_AT(1024u);
     // ---- every long-latency load of the tile is issued here, before any use ---------
     // Register sets of the wavefront's slices.  Slice 0 -- the widest -- takes sets 0 and 1 (its alignments 0..7 and
     // 8..15, fold_first); slices 1 .. kTop are loaded HERE into sets 2 .., the others later, into the sets the fold
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
         dict_v[u] = (kDict != kWPlain && tx + u * kTileThreads < (uint32_t)dict_entries<kDict>()) ? dict[tx + u * kTileThreads] : 0.0f;
     SliceRegs<WT, kCh> R[kSets];
     auto load_slices = [&]() {
+        if (OEM_EXP(4096u)) return; // (cost attribution: no slice is requested)
         load_slice<WT, kCh, kNT, kDict>(R[0], w + (size_t)woff[0] * 64, codes + (size_t)coff[0] * 64, lane, wid[0], iptr(0));
         // alignments 8..15 of the first slice, into the second set (see fold_first)
         load_slice<WT, kCh, kNT, kDict>(R[1], w + ((size_t)woff[0] + kCh) * 64, codes + ((size_t)coff[0] + kCh / 2) * 64, lane,
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
             for (int k = 0; k < kRem; ++k) {
                 const uint32_t i = tx + k * kTileThreads;
                 const uint32_t o = td.remote_begin + (i < td.remote_cnt ? i : last);
+                if (OEM_EXP(8192u)) { rt[k] = td.b_min << kBucketShift; rrow[k] = 0; ri[k] = 0u; rw[k] = (WT)0; continue; } // (no record is requested)
                 ld_remote<kPacked, kNT && OEM_REC_NT>(r_a, r_row, o, tid_base, rt[k], rrow[k]);
                 if (kRemIdx) ri[k] = ld_stream<kNT && OEM_REC_NT>(&r_wi[o]);
                 else rw[k] = ld_stream<kNT && OEM_REC_NT>(&r_w[o]);
@@ -261,6 +276,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(2); // theta window landed and written to LDS, windows cleared (remote gathers may still be in flight)
     __syncthreads();
     OEM_PROBE(3);
+    OEM_EXIT_AT(128u);
     if (rd_prev && rd_i0 < rd_i1 && (tx & ~63u) < rd_i1 - rd_i0) { // wave-uniform: the wavefronts that hold a share.
         double rel = 0.0;                                          // em.rs:194-201 (signed, floored at 0 by the maximum),
         if (rd_i0 + tx < rd_i1) {                                  // :207 for the buffer that rests
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     OEM_PROBE(4); // remote gathers landed, their denominator atomics issued
     __syncthreads();
     OEM_PROBE(5);
+    OEM_EXIT_AT(256u);
 
     // ---- local alignments: one read per lane, all operands already in registers -----
     // slice 0: 16 register-resident alignments in sets 0 and 1; it releases set 0 to the first late slice half way
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
     __syncthreads();
     OEM_PROBE(10);
+    OEM_EXIT_AT(512u);
 
     // ---- remote alignments, phase B: queue <- x * (c_i / denom_i) ------------------
 #pragma unroll
