@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 
     uint32_t rrow[kRem];  // their read (index inside the tile)
     uint32_t rslot[kRem]; // their slot in the bucket-major queue
+    uint32_t rwi[kRem];   // coded stores: the table index of their weight (looked up in LDS behind the first barrier)
     constexpr bool kRemIdx = kDict == kWBytes || kDict == kWFused; // byte-coded stores: a remote record's weight is a table index byte too
     const uint32_t tid_base = td.problem * problem_size; // first transcript of the tile's EM problem (0: one problem)
     const uint32_t *sd_t = sd + td.sd_begin - td.b_min;  // slot of record i = sd_t[bucket of its transcript] + i
@@ -244,10 +245,14 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
 #pragma unroll
             for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; ri[k] = 0u; rrow[k] = 0; }
         }
-        // (coded: the weight comes from the 1 KiB table in memory -- L1-resident -- in the same round trip as theta)
 #pragma unroll
         for (int k = 0; k < kRem; ++k)
-            rx[k] = th(OEM_EXP(16u) ? 1.0 : theta[rt[k]]) * (kRemIdx ? (double)dict[ri[k]] : (double)rw[k]);
+        {
+            // (coded: the weight is looked up in the LDS copy of the table at the start of phase A -- as a global
+            // gather it was one more vector-memory instruction per record in the prologue)
+            rx[k] = th(OEM_EXP(16u) ? 1.0 : theta[rt[k]]) * (kRemIdx ? 1.0 : (double)rw[k]);
+            rwi[k] = ri[k];
+        }
         // the slots are wanted last (phase B): a few words per tile, cache-resident.  Branch-free and back to
         // back -- a lookup per branch made the compiler wait for each one in turn, six dependent round trips
         // (a tile without remote records reads the table's slack word)
@@ -294,6 +299,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     }
 
     // ---- remote alignments, phase A: denominators --------------------------------
+    if (kRemIdx) {
+#pragma unroll
+        for (int k = 0; k < kRem; ++k) rx[k] *= (double)dict_l[rwi[k]]; // (index 0 = 0.0: a thread without a record)
+    }
 #pragma unroll
     for (int k = 0; k < kRem; ++k)
         if (tx + k * kTileThreads < td.remote_cnt && !OEM_EXP(2u)) lds_add_f64(&den_l[rrow[k]], rx[k]);
