@@ -468,17 +468,15 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
             else rw[k] = ld_stream_b<kNT && OEM_REC_NT>(&r_w[o]);
         }
         load_slices();
-        if (kFused) { // (the table is a few cache lines: a second, short round trip)
-#pragma unroll
-            for (int k = 0; k < kRem; ++k) rw[k] = (WT)dict[ri[k]];
-        }
+        // (kFused: the weight is read from the LDS copy of the table behind the first barrier -- index 0 = 0.0 for a
+        // thread without a record; as a global gather it was one more vector-memory instruction per record up here)
 #pragma unroll
         for (int k = 0; k < kRem; ++k)
-            if (tx + k * kTileThreadsE >= td.remote_cnt) rw[k] = (WT)0;
+            if (tx + k * kTileThreadsE >= td.remote_cnt) { rw[k] = (WT)0; ri[k] = 0u; }
     } else {
         load_slices();
 #pragma unroll
-        for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; rrow[k] = 0; }
+        for (int k = 0; k < kRem; ++k) { rt[k] = td.b_min << kBucketShift; rw[k] = (WT)0; ri[k] = 0u; rrow[k] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < kRem; ++k) rslot[k] = 0;
@@ -561,6 +559,10 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
         OEM_PROBE_E(3);
 
         // ---- remote phase A: denominators ------------------------------------------------
+        if (kFused) {
+#pragma unroll
+            for (int k = 0; k < kRem; ++k) rw[k] = (WT)dict_l[ri[k]];
+        }
 #pragma unroll
         for (int k = 0; k < kRem; ++k)
             if (rmult[k]) {
