@@ -90,17 +90,43 @@ static int run_em_deferred(oem_store *s, const RunArgs &a, oem_run_info *info)
     OEM_TRY(prepare_row_w(s, a));
     // iteration j is decided by pass j + 1: max_iter iterations take max_iter + 1 passes
     const uint64_t n_total = a.max_iter ? (uint64_t)a.max_iter + 1 : 0;
+    // The host stays ONE chunk ahead of its look at the state: the next 16 passes are in the queue before it waits for
+    // the copy taken behind the previous ones, so the device never idles for the host's round trip (passes launched
+    // after the rule has fired return at once: at most a chunk of empty launches per run).
     uint64_t launched = 0;
-    while (launched < n_total) {
+    auto enqueue_chunk = [&]() -> int {
         uint64_t chunk = launched == 0 ? (uint64_t)a.min_iter_gate + 3 : 16;
         if (chunk > n_total - launched) chunk = n_total - launched;
         if (chunk > 4096) chunk = 4096;
         for (uint64_t k = 0; k < chunk; ++k) OEM_TRY(enqueue_deferred_pass(s, a, p, bufs, launched + k));
         launched += chunk;
-        OEM_HIP(hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream));
-        OEM_HIP(hipStreamSynchronize(s->stream));
-        if (s->h_state->done) break;
+        return OEM_OK;
+    };
+    hipEvent_t seen = nullptr;
+    if (n_total) OEM_HIP(hipEventCreateWithFlags(&seen, hipEventDisableTiming));
+    int rc = OEM_OK;
+    if (n_total) {
+        rc = enqueue_chunk();
+        while (rc == OEM_OK) {
+            // a copy of the state as the passes enqueued so far leave it ...
+            if (hipMemcpyAsync(s->h_state, s->d_state, sizeof(EmState), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipEventRecord(seen, s->stream) != hipSuccess) {
+                rc = fail(OEM_ERR_HIP, "oem_em_run: state copy failed");
+                break;
+            }
+            // ... and the next chunk behind it, before the host waits for that copy
+            const bool more = launched < n_total;
+            if (more) rc = enqueue_chunk();
+            if (rc != OEM_OK) break;
+            if (hipEventSynchronize(seen) != hipSuccess) {
+                rc = fail(OEM_ERR_HIP, "oem_em_run: waiting for the loop state failed");
+                break;
+            }
+            if (s->h_state->done || !more) break;
+        }
     }
+    if (seen) hipEventDestroy(seen);
+    if (rc != OEM_OK) return rc;
     if (n_total && !s->h_state->done) return fail(OEM_ERR_STATE, "the deferred stopping rule did not fire within max_iter + 1 passes");
     const uint32_t f = n_total ? s->h_state->pad[0] - 1u : 0u; // the buffer of the final abundances
     if (f > 2u) return fail(OEM_ERR_STATE, "the deferred stopping rule left no final buffer");
