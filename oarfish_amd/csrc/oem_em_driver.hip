@@ -50,10 +50,25 @@ int enqueue_iteration(oem_store *s, const RunArgs &a, const EmParams &p)
 // vectors rotate), and the first workgroup of pass i + 1's fold applies the rule (DeferredRelDiff, oem_internal.h).
 // If it says stop, pass i + 1 was speculative and its accumulator is dropped: the loop has run the reference's
 // iterations, stopped where the reference stops, and theta is what the reference holds at that point; the cost is one
-// pass per run.  Single-device stores on the tiled path; row shards keep the sweep (it carries their exchange).
+// pass per run that CONVERGES.  A run that reaches max_iter pays nothing: when pass max_iter would be due the loop ends
+// whatever the comparison says (em.rs:181), so its last iteration is decided by a sweep over the two vectors alone
+// (k_deferred_sweep) -- max_iter iterations are max_iter passes + one 3 us kernel.  Single-device stores on the tiled
+// path; row shards keep the sweep of every iteration (it carries their exchange).
+//
+// What "speculative" obliges (the kernels rely on it, nothing else enforces it): (1) the workgroup that decides writes
+// `done` while the other workgroups of the SAME fold launch may already have read it as 0 or still read it as 1, so the
+// accumulator of a deciding pass can be folded in part -- it is `rest` below and is never read; (2) a tile workgroup
+// must look at `done` BEFORE it zeroes its share of rd_prev (k_em_tile returns at the top), or the empty launches behind
+// the decision would wipe the buffer the final pass accumulates into and, one launch later, the final theta.
+#ifndef OEM_DEFERRED_DEFAULT
+#define OEM_DEFERRED_DEFAULT 1 // (scripts/build_variant.sh: 0 builds the classic loop into the product library for an A/B)
+#endif
 bool deferred_reldiff_ok(const oem_store *s, const RunArgs &a)
 {
-    return use_tiled(s, a) && !comm_exchanges(s->comm) && !graph_ok(s) && knob("OEM_DEFERRED_RELDIFF", 1) != 0;
+    // (a store whose reads are all empty has a tiled layout without tiles: its passes launch nothing that could carry
+    // the decision -- the classic loop's sweep returns the reference's zeros)
+    return use_tiled(s, a) && s->tiled.n_tiles > 0 && !comm_exchanges(s->comm) && !graph_ok(s) &&
+           knob("OEM_DEFERRED_RELDIFF", OEM_DEFERRED_DEFAULT) != 0;
 }
 
 int ensure_deferred(oem_store *s)
@@ -63,10 +78,12 @@ int ensure_deferred(oem_store *s)
     return OEM_OK;
 }
 
-// pass i of a deferred run: theta_i in bufs[i % 3], accumulator bufs[(i + 1) % 3], theta_{i-1} in bufs[(i + 2) % 3]
+// pass i of a deferred run: theta_i in bufs[i % 3], accumulator bufs[(i + 1) % 3], theta_{i-1} in bufs[(i + 2) % 3].
+// i == max_iter is not a pass: iteration max_iter - 1 is decided by the sweep alone (the loop ends there either way).
 int enqueue_deferred_pass(oem_store *s, const RunArgs &a, const EmParams &p, double *const bufs[3], uint64_t i)
 {
     DeferredRelDiff rd{i > 0 ? bufs[(i + 2) % 3] : nullptr, s->rel_slots, s->d_state, p, 1u + (uint32_t)(i % 3)};
+    if (i > 0 && i == p.max_iter) return launch_deferred_sweep(s, rd.prev, bufs[i % 3], rd);
     return launch_em_pass_tiled(s, bufs[i % 3], bufs[(i + 1) % 3], s->d_state, a.d_row_w ? s->tiled.row_w_perm : nullptr,
                                 nullptr, 0, false, &rd);
 }
@@ -77,18 +94,11 @@ static int run_em_deferred(oem_store *s, const RunArgs &a, oem_run_info *info)
     EmParams p{T, a.max_iter, a.min_iter_gate, a.conv_thresh};
     OEM_TRY(ensure_deferred(s));
     double *const bufs[3] = {s->theta, s->cnt, s->third};
-    if (a.init) {
-        OEM_HIP(hipMemcpyAsync(bufs[0], a.init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
-    } else {
-        OEM_TRY(launch_fill(s, bufs[0], (double)a.total_reads / (double)T, T)); // em.rs:165
-    }
-    OEM_HIP(hipMemsetAsync(bufs[1], 0, sizeof(double) * T, s->stream));
-    OEM_HIP(hipMemsetAsync(bufs[2], 0, sizeof(double) * T, s->stream));
-    OEM_HIP(hipMemsetAsync(s->rel_slots, 0, sizeof(unsigned long long) * kRelSlots, s->stream));
-    OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
+    if (a.init) OEM_HIP(hipMemcpyAsync(bufs[0], a.init, sizeof(double) * T, hipMemcpyHostToDevice, s->stream));
+    OEM_TRY(launch_deferred_init(s, bufs, (double)a.total_reads / (double)T, a.init == nullptr)); // em.rs:160-166
     std::memset(s->h_state, 0, sizeof(EmState));
     OEM_TRY(prepare_row_w(s, a));
-    // iteration j is decided by pass j + 1: max_iter iterations take max_iter + 1 passes
+    // iteration j is decided by launch j + 1: max_iter iterations take max_iter passes + the sweep that decides the last
     const uint64_t n_total = a.max_iter ? (uint64_t)a.max_iter + 1 : 0;
     // The host stays ONE chunk ahead of its look at the state: the next 16 passes are in the queue before it waits for
     // the copy taken behind the previous ones, so the device never idles for the host's round trip (passes launched
@@ -127,11 +137,11 @@ static int run_em_deferred(oem_store *s, const RunArgs &a, oem_run_info *info)
     }
     if (seen) hipEventDestroy(seen);
     if (rc != OEM_OK) return rc;
-    if (n_total && !s->h_state->done) return fail(OEM_ERR_STATE, "the deferred stopping rule did not fire within max_iter + 1 passes");
+    if (n_total && !s->h_state->done) return fail(OEM_ERR_STATE, "the deferred stopping rule did not fire within max_iter passes and the last sweep");
     const uint32_t f = n_total ? s->h_state->pad[0] - 1u : 0u; // the buffer of the final abundances
     if (f > 2u) return fail(OEM_ERR_STATE, "the deferred stopping rule left no final buffer");
-    // final: em.rs:238-252.  The buffer behind theta's was zeroed by the pass that decided; the one ahead holds that
-    // pass's speculative counts and rests.
+    // final: em.rs:238-252.  The buffer behind theta's was zeroed by the launch that decided; the one ahead holds that
+    // pass's speculative counts (nothing, when the last sweep decided) and rests.
     double *theta = bufs[f], *cnt = bufs[(f + 2) % 3], *rest = bufs[(f + 1) % 3];
     OEM_TRY(launch_zero_small(s, theta, cnt, T));
     s->theta = theta;

@@ -411,6 +411,57 @@ __global__ __launch_bounds__(64) void k_deferred_decide(unsigned long long *slot
     deferred_decide(slots, state, p, decide);
 }
 
+// The LAST iteration of a run that reaches max_iter, decided without a pass.  When pass max_iter would be due the loop
+// ends whatever the rel-diff says (em.rs:181) and theta_{max_iter} is final either way (the swap of em.rs:204 comes
+// before the break of :212); only `converged`, `niter` and `rel_diff` of oem_run_info hang on that last comparison.
+// So instead of a speculative pass whose counts are dropped (0.146 ms at C3, 27 us at C2) this sweep takes the rel-diff
+// of theta_{N-1} (`prev`) against theta_N (`cur`) -- the tile workgroups' share of the work in k_em_tile -- zeroes
+// `prev` (the accumulator of the final pass, em.rs:245) and its last workgroup applies the rule.  Election as in
+// k_reldiff_swap_clear (oem_kernels.hip): the maxima are device-scope atomics drained before the ticket is taken.
+constexpr int kSweepThreads = 256;
+__global__ __launch_bounds__(kSweepThreads) void k_deferred_sweep(double *__restrict__ prev, const double *__restrict__ cur,
+                                                                  unsigned long long *slots, EmState *state, EmParams p,
+                                                                  uint32_t decide)
+{
+    if (state->done) return;
+    double rel = 0.0;
+    const uint32_t stride = gridDim.x * kSweepThreads;
+    for (uint32_t i0 = blockIdx.x * kSweepThreads + threadIdx.x; i0 < p.n_txps; i0 += 4 * stride) {
+        double pc[4], cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // (all eight loads in flight before the first use)
+            const uint32_t i = i0 + k * stride, ic = i < p.n_txps ? i : i0;
+            pc[k] = prev[ic];
+            cc[k] = cur[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * stride;
+            if (i < p.n_txps) {
+                if (pc[k] > OEM_MIN_READ_THRESH) rel = fmax(rel, (cc[k] - pc[k]) / pc[k]); // em.rs:195-199 (signed)
+                prev[i] = 0.0;                                                             // em.rs:207
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+    __shared__ double smax[kSweepThreads / 64];
+    __shared__ bool is_last;
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = rel;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = smax[0];
+        for (int i = 1; i < kSweepThreads / 64; ++i) m = fmax(m, smax[i]);
+        if (m > 0.0) atomicMax(&slots[blockIdx.x & (kRelSlots - 1u)], (unsigned long long)__double_as_longlong(m));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = atomicAdd(&state->blocks_arrived, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x < 64) {
+        if (threadIdx.x == 0) state->blocks_arrived = 0u;
+        deferred_decide(slots, state, p, decide);
+    }
+}
+
 // kNTQ: the queue range is read non-temporally.  Measured both ways (profiles/r04_notes.md): a store that fits the
 // Infinity Cache with room to spare (C2: 1 M reads) gains 2.7 % of its pass -- the entries are read once and theta and the
 // counts keep the L2 -- while at C3 the fold finds the entries the tile kernel has just written in the caches, and
@@ -606,6 +657,48 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
         hipLaunchKernelGGL(k_deferred_decide, dim3(1), dim3(64), 0, s->stream, rd_slots, rd_state, rd_p, rd_decide);
         OEM_HIP(hipGetLastError());
     }
+    return OEM_OK;
+}
+
+// The start of a deferred run in one launch (it was a fill, four memsets: five launch boundaries and ~50 us of host time
+// in front of every run, 2.5 us per step of a 20-iteration one): theta_0 = `avg` everywhere (em.rs:165; `fill` false:
+// the caller's init_abundances are already in b0), the two other vectors, the slots and the loop state zeroed.
+__global__ __launch_bounds__(256) void k_deferred_init(double *__restrict__ b0, double *__restrict__ b1, double *__restrict__ b2,
+                                                       double avg, bool fill, uint32_t n_txps, unsigned long long *slots,
+                                                       EmState *state)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_txps; i += gridDim.x * 256u) {
+        if (fill) b0[i] = avg;
+        b1[i] = 0.0;
+        b2[i] = 0.0;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kRelSlots) slots[threadIdx.x] = 0ull;
+        static_assert(sizeof(EmState) % 4 == 0 && sizeof(EmState) / 4 <= 256, "EmState cleared by one workgroup");
+        if (threadIdx.x < sizeof(EmState) / 4) reinterpret_cast<uint32_t *>(state)[threadIdx.x] = 0u;
+    }
+}
+
+int launch_deferred_init(oem_store *s, double *const bufs[3], double avg, bool fill)
+{
+    const uint32_t T = s->csr.n_txps;
+    uint32_t grid = (T + 1023) / 1024;
+    if (grid > 512) grid = 512;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_deferred_init, dim3(grid), dim3(256), 0, s->stream, bufs[0], bufs[1], bufs[2], avg, fill, T, s->rel_slots,
+                       s->d_state);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
+int launch_deferred_sweep(oem_store *s, double *prev, const double *cur, const DeferredRelDiff &rd)
+{
+    const uint32_t T = rd.p.n_txps;
+    uint32_t grid = (T + 4 * kSweepThreads - 1) / (4 * kSweepThreads);
+    if (grid > 256) grid = 256;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_deferred_sweep, dim3(grid), dim3(kSweepThreads), 0, s->stream, prev, cur, rd.slots, rd.state, rd.p, rd.decide);
+    OEM_HIP(hipGetLastError());
     return OEM_OK;
 }
 

@@ -6,6 +6,34 @@
 
 using namespace oem;
 
+namespace {
+// the two events of a timed region; destroyed on every path out of the entry point
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair &) = delete;
+    EventPair &operator=(const EventPair &) = delete;
+    ~EventPair()
+    {
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+    }
+    int create()
+    {
+        OEM_HIP(hipEventCreate(&e0));
+        OEM_HIP(hipEventCreate(&e1));
+        return OEM_OK;
+    }
+    // waits for e1; milliseconds between the two
+    int elapsed(float *ms)
+    {
+        OEM_HIP(hipEventSynchronize(e1));
+        OEM_HIP(hipEventElapsedTime(ms, e0, e1));
+        return OEM_OK;
+    }
+};
+} // namespace
+
 // ---------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------
@@ -18,9 +46,8 @@ extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg
     const uint32_t T = s->csr.n_txps;
     OEM_TRY(launch_fill(s, s->theta, (double)s->global_n_reads / (double)T, T));
     OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
-    hipEvent_t e0, e1;
-    OEM_HIP(hipEventCreate(&e0));
-    OEM_HIP(hipEventCreate(&e1));
+    EventPair ev;
+    OEM_TRY(ev.create());
     RunArgs a;
     a.row_end = s->csr.n_reads;
     // one untimed launch to page the kernel in
@@ -33,18 +60,15 @@ extern "C" int oem_time_m_step(oem_store *s, uint32_t n_launches, float *out_avg
         OEM_TRY(capture_chunk(s->stream, kPer, [&]() { return enqueue_pass(s, a, nullptr); }, &cg));
     if (cg.ready()) {
         OEM_HIP(hipGraphLaunch(cg.ge, s->stream)); // untimed: upload
-        OEM_HIP(hipEventRecord(e0, s->stream));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
         for (uint32_t k = 0; k < n_launches; k += kPer) OEM_HIP(hipGraphLaunch(cg.ge, s->stream));
     } else {
-        OEM_HIP(hipEventRecord(e0, s->stream));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
         for (uint32_t k = 0; k < n_launches; ++k) OEM_TRY(enqueue_pass(s, a, nullptr));
     }
-    OEM_HIP(hipEventRecord(e1, s->stream));
-    OEM_HIP(hipEventSynchronize(e1));
+    OEM_HIP(hipEventRecord(ev.e1, s->stream));
     float ms = 0.f;
-    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    OEM_TRY(ev.elapsed(&ms));
     *out_avg_ms = ms / (float)n_launches;
     return OEM_OK;
     OEM_API_END("oem_time_m_step")
@@ -63,56 +87,35 @@ extern "C" int oem_time_em_iters(oem_store *s, uint32_t n_iters, float *out_ms)
     a.max_iter = n_iters;
     a.conv_thresh = -1.0; // rel_diff >= 0 is never < -1: no early exit (SURVEY.md 8a note 3)
     EmParams p{T, a.max_iter, 0xffffffffu, a.conv_thresh};
+    EventPair ev;
+    OEM_TRY(ev.create());
+    if (deferred_reldiff_ok(s, a)) { // as oem_em_run runs them: n_iters passes, the rule one pass behind, the last iteration decided by the sweep
+        OEM_TRY(ensure_deferred(s));
+        double *const bufs[3] = {s->theta, s->cnt, s->third};
+        OEM_TRY(launch_deferred_init(s, bufs, (double)a.total_reads / (double)T, true));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
+        for (uint64_t k = 0; k <= n_iters; ++k) OEM_TRY(enqueue_deferred_pass(s, a, p, bufs, k));
+        OEM_HIP(hipEventRecord(ev.e1, s->stream));
+        return ev.elapsed(out_ms);
+    }
     OEM_TRY(launch_fill(s, s->theta, (double)a.total_reads / (double)T, T));
     OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
     OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
-    hipEvent_t e0, e1;
-    OEM_HIP(hipEventCreate(&e0));
-    OEM_HIP(hipEventCreate(&e1));
-    if (deferred_reldiff_ok(s, a)) { // as oem_em_run runs them: n_iters iterations = n_iters + 1 passes, the rule one pass behind
-        OEM_TRY(ensure_deferred(s));
-        double *const bufs[3] = {s->theta, s->cnt, s->third};
-        OEM_HIP(hipMemsetAsync(bufs[2], 0, sizeof(double) * T, s->stream));
-        OEM_HIP(hipMemsetAsync(s->rel_slots, 0, sizeof(unsigned long long) * kRelSlots, s->stream));
-        OEM_HIP(hipEventRecord(e0, s->stream));
-        for (uint64_t k = 0; k <= n_iters; ++k) OEM_TRY(enqueue_deferred_pass(s, a, p, bufs, k));
-        OEM_HIP(hipEventRecord(e1, s->stream));
-        OEM_HIP(hipEventSynchronize(e1));
-        float dms = 0.f;
-        OEM_HIP(hipEventElapsedTime(&dms, e0, e1));
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-        *out_ms = dms;
-        return OEM_OK;
-    }
-    OEM_HIP(hipEventRecord(e0, s->stream));
+    OEM_HIP(hipEventRecord(ev.e0, s->stream));
     ChunkGraph cg; // launched the way oem_em_run launches: chunks of kGraphIters iterations from a graph
     if (graph_ok(s) && n_iters >= kGraphIters && n_iters % kGraphIters == 0)
         OEM_TRY(capture_chunk(s->stream, kGraphIters, [&]() { return enqueue_iteration(s, a, p); }, &cg));
     if (cg.ready()) {
         OEM_HIP(hipGraphLaunch(cg.ge, s->stream)); // untimed: the first launch of an executable graph uploads it
         OEM_HIP(hipMemsetAsync(s->d_state, 0, sizeof(EmState), s->stream));
-        OEM_HIP(hipEventRecord(e0, s->stream));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
         for (uint32_t k = 0; k < n_iters; k += kGraphIters) OEM_HIP(hipGraphLaunch(cg.ge, s->stream));
-        OEM_HIP(hipEventRecord(e1, s->stream));
-        OEM_HIP(hipEventSynchronize(e1));
-        float gms = 0.f;
-        OEM_HIP(hipEventElapsedTime(&gms, e0, e1));
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-        OEM_TRY(comm_check(s->comm, s->stream));
-        *out_ms = gms;
-        return OEM_OK;
+    } else {
+        for (uint32_t k = 0; k < n_iters; ++k) OEM_TRY(enqueue_iteration(s, a, p));
     }
-    for (uint32_t k = 0; k < n_iters; ++k) OEM_TRY(enqueue_iteration(s, a, p));
-    OEM_HIP(hipEventRecord(e1, s->stream));
-    OEM_HIP(hipEventSynchronize(e1));
-    float ms = 0.f;
-    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    *out_ms = ms;
-    return OEM_OK;
+    OEM_HIP(hipEventRecord(ev.e1, s->stream));
+    OEM_TRY(ev.elapsed(out_ms));
+    return comm_check(s->comm, s->stream);
     OEM_API_END("oem_time_em_iters")
 }
 
@@ -125,18 +128,14 @@ extern "C" int oem_time_allreduce(oem_store *s, uint32_t n_calls, float *out_avg
     if (!comm_exchanges(s->comm)) return fail(OEM_ERR_STATE, "oem_time_allreduce: no communicator attached");
     const uint32_t T = s->csr.n_txps;
     OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
-    hipEvent_t e0, e1;
-    OEM_HIP(hipEventCreate(&e0));
-    OEM_HIP(hipEventCreate(&e1));
+    EventPair ev;
+    OEM_TRY(ev.create());
     OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream)); // untimed: first-use set-up
-    OEM_HIP(hipEventRecord(e0, s->stream));
+    OEM_HIP(hipEventRecord(ev.e0, s->stream));
     for (uint32_t k = 0; k < n_calls; ++k) OEM_TRY(comm_allreduce_sum_f64(s->comm, s->cnt, s->cnt, T, s->stream));
-    OEM_HIP(hipEventRecord(e1, s->stream));
-    OEM_HIP(hipEventSynchronize(e1));
+    OEM_HIP(hipEventRecord(ev.e1, s->stream));
     float ms = 0.f;
-    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    OEM_TRY(ev.elapsed(&ms));
     OEM_TRY(comm_check(s->comm, s->stream));
     *out_avg_us = ms * 1e3f / (float)n_calls;
     return OEM_OK;
@@ -178,9 +177,8 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
     }
     OEM_HIP(hipMemcpyAsync(bb.state, bb.h_state, sizeof(BatchState) * kBatch, hipMemcpyHostToDevice, s->stream));
     EmParams p{T, 0xffffffffu, 0xffffffffu, -1.0}; // no slot ever stops (SURVEY.md 8a note 3)
-    hipEvent_t e0, e1;
-    OEM_HIP(hipEventCreate(&e0));
-    OEM_HIP(hipEventCreate(&e1));
+    EventPair ev;
+    OEM_TRY(ev.create());
     OEM_TRY(launch_batch_pass(s, bb)); // one untimed pass
     OEM_TRY(launch_batch_reldiff(s, bb, p));
     auto one_pass = [&]() -> int {
@@ -192,18 +190,15 @@ extern "C" int oem_time_bootstrap_passes(oem_store *s, uint32_t n_passes, float 
     if (graph_ok(s) && n_passes % kPer == 0) OEM_TRY(capture_chunk(s->stream, kPer, one_pass, &cg));
     if (cg.ready()) {
         OEM_HIP(hipGraphLaunch(cg.ge, s->stream)); // untimed: upload
-        OEM_HIP(hipEventRecord(e0, s->stream));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
         for (uint32_t i = 0; i < n_passes; i += kPer) OEM_HIP(hipGraphLaunch(cg.ge, s->stream));
     } else {
-        OEM_HIP(hipEventRecord(e0, s->stream));
+        OEM_HIP(hipEventRecord(ev.e0, s->stream));
         for (uint32_t i = 0; i < n_passes; ++i) OEM_TRY(one_pass());
     }
-    OEM_HIP(hipEventRecord(e1, s->stream));
-    OEM_HIP(hipEventSynchronize(e1));
+    OEM_HIP(hipEventRecord(ev.e1, s->stream));
     float ms = 0.f;
-    OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    OEM_TRY(ev.elapsed(&ms));
     *out_avg_ms = ms / (float)n_passes;
     if (out_slots) *out_slots = kBatch;
     if (out_algorithmic_bytes) {

@@ -676,6 +676,15 @@ def test_edge_cases():
     with DeviceStore(np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:
         cnt, info = d.em_run(None, 10, 1e-3, 50)
         assert np.all(cnt == 0.0) and info.n_passes == 11
+    # reads but no alignment at all: a tiled layout without tiles -- no launch could carry a deferred decision, the
+    # classic loop's sweep returns the reference's zeros (em.rs: every denom is an empty sum)
+    with DeviceStore(np.zeros(6, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4) as d:
+        o0 = c_oracle.Store(np.zeros(6, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), None, 4)
+        for m in (0, 1, 2, 3, 10):
+            cnt, info = d.em_run(None, m, 1e-3, 1)
+            wo, wi = c_oracle.do_em(o0, max_iter=m, conv_thresh=1e-3, min_iter_gate=1)
+            assert np.all(cnt == 0.0) and np.all(wo == 0.0)
+            assert (info.niter, info.n_passes, info.converged) == (wi.niter, wi.n_passes, wi.converged), m
     # empty rows are tolerated and contribute nothing
     rp = np.array([0, 0, 2, 2, 3], dtype=np.uint64)
     tid = np.array([0, 1, 1], dtype=np.uint32)
