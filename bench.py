@@ -61,6 +61,7 @@ def parse(argv=None):
                          "over 8 GPUs, 16 otherwise)")
     ap.add_argument("--cell-reads", type=int, default=None, help="reads per cell (default 50000; tiny: 2000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the configs[1] leg and the N = 8 shard leg")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="do not bind the process to the CPUs of the GPU's NUMA node (see bind_to_gpu_numa_node)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -496,6 +497,9 @@ def main():
             threads = max(2, min(32, os.cpu_count() or 8))
             cv = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], coverage=True, threads=threads)
             timed("coverage", cv.row_ptr, cv.tid, cv.as_prob, cv.cov_prob)
+            # the same store with the opt-in oem_store_opts.weight_coding = 2: the static weight p * cov rounded once to
+            # f32 (<= 6e-8 relative per weight; SURVEY 8a note 2), 8 B per alignment through the f32 kernels
+            timed("coverage_f32w", cv.row_ptr, cv.tid, cv.as_prob, cv.cov_prob, weight_coding=2)
             del cv
             ug = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=threads, gaps="uniform")
             timed("uniform_gaps", ug.row_ptr, ug.tid, ug.as_prob, None)
@@ -530,6 +534,14 @@ def main():
     n_cells = args.cells if args.cells is not None else (625 if args.workload == "c3" else 16)
     if n_cells > 0:
         cells = cells_leg(args, n_cells, rank, world, local_rank, sync, max_over_ranks)
+
+    # BASELINE configs[1] (1 M reads x 60 k transcripts, 1000 EM iterations) and the shard one of eight ranks would own
+    # (configs[3]): both are ONE wave of workgroups deep -- the regime where a tile's chain, not the memory system, sets
+    # the pass -- and were builder-only figures until round 6
+    c2 = shard_n8 = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_side_legs:
+        c2 = c2_leg(local_rank, sync)
+        shard_n8 = shard_leg(full, cfg, 8, local_rank)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -585,6 +597,8 @@ def main():
             "bootstraps": boots,
             "cells": cells,
             "em_to_convergence": conv,
+            "c2": c2,
+            "shard_n8": shard_n8,
         }
         print(json.dumps(out))
     store.close()
@@ -592,6 +606,56 @@ def main():
         comm.close()
     if dist_mode:
         dist.destroy_process_group()
+
+
+def c2_leg(local_rank, sync):
+    """BASELINE configs[1]: synthetic 1 M reads x 60 k transcripts (avg 8 alignments per read), one GPU, 1000 EM
+    iterations (max_iter 1000, threshold 0: SURVEY 8a note 3) through oem_em_run -- wall time of the whole call, result
+    copied out -- plus the HIP-event-timed pass and loop iteration and the pass's fraction of the HBM peak (the store's
+    69 MB fit the Infinity Cache: a fraction above 1 would be possible here and is far away)."""
+    from oarfish_amd import synth
+    from oarfish_amd.types import DeviceStore
+    cfg = WORKLOADS["c2"]
+    st = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=max(2, min(32, os.cpu_count() or 8)))
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps, device=local_rank) as d:
+        d.time_m_step(500)                                   # settle (see SETTLE_PASSES)
+        pass_ms = min(d.time_m_step(200) for _ in range(3))
+        it_ms = min(d.time_em_iters(1000) for _ in range(3)) / 1000
+        _h, alg = d.bytes()
+        d.em_run(None, 100, 0.0, 50)
+        best, info = None, None
+        for _ in range(3):
+            sync()
+            t = time.perf_counter()
+            _cnt, info = d.em_run(None, 1000, 0.0, 50)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return dict(workload=cfg["name"], value=1000 / best, unit="EM iterations/s", iterations=int(info.niter),
+                    n_passes=int(info.n_passes), em_run_seconds=best, kernel_avg_ms=pass_ms, device_ms_per_step=it_ms,
+                    algorithmic_bytes_per_launch=alg, frac=alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    alignments=int(st.tid.size), tiles=d.info(_lib_const("OEM_INFO_TILES")),
+                    note="value = 1000 iterations / wall time of one oem_em_run call (best of 3), counts copied out; "
+                         "kernel_avg_ms = one E/M pass (HIP events, best of 3 x 200 launches)")
+
+
+def _lib_const(name):
+    from oarfish_amd import _lib
+    return getattr(_lib, name)
+
+
+def shard_leg(full, cfg, n, local_rank):
+    """What rank 0 of `n` would compute per iteration of configs[3]: its nnz-balanced row shard of the C3 store as an
+    un-attached store on this GPU -- E/M pass (tile kernel + fold: what a row shard's iteration has in front of its
+    exchange kernels) and the single-device loop iteration, HIP-event-timed.  No exchange: one GPU."""
+    from oarfish_amd import dist as odist
+    from oarfish_amd.types import DeviceStore
+    sh = odist.shard_rows_by_nnz(full.row_ptr, full.tid, full.as_prob, None, 0, n)
+    with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, cfg["n_txps"], device=local_rank) as d:
+        d.time_m_step(500)
+        pass_us = min(d.time_m_step(200) for _ in range(3)) * 1e3
+        it_us = min(d.time_em_iters(500) for _ in range(3)) / 500 * 1e3
+        return dict(n=n, reads=int(sh.row_end - sh.row_begin), alignments=int(sh.tid.size), pass_us=pass_us,
+                    iteration_us=it_us, note="rank 0's row shard as an un-attached store: no exchange in these figures")
 
 
 def pick_exchange(store, comm, dist, torch, have_rccl=True, cpu_group=False):

@@ -307,6 +307,24 @@ int create_store_impl(const uint64_t *row_ptr, const uint32_t *tid, const float 
                       const double *cov_prob, uint64_t n_reads, uint64_t nnz, uint32_t n_txps,
                       int device, const oem_store_opts *opts, oem_store *s, const CellRelabel *relabel)
 {
+    // weight_coding = 2 (opt-in): with the coverage model the iteration-invariant weight w = (p as f64) * cov
+    // (em.rs:107-111) is rounded ONCE to f32 and the store is an f32 store -- 8 B per alignment instead of 12, the
+    // kernels of the plain f32 stream instead of the f64 ones.  Every product and sum of the EM stays f64; only the
+    // stored static factor carries a relative error of at most 2^-24 = 6e-8 (SURVEY.md 8a note 2; products below
+    // 1.2e-38 go through f32's denormals, below 1.4e-45 to zero).  Without a coverage column it is coding 0.
+    std::vector<float> w_rounded;
+    oem_store_opts o2;
+    if (opts && opts->weight_coding == 2) {
+        o2 = *opts;
+        o2.weight_coding = cov_prob ? 1u : 0u;
+        opts = &o2;
+        if (cov_prob) {
+            w_rounded.resize(nnz);
+            for (uint64_t j = 0; j < nnz; ++j) w_rounded[j] = (float)((double)as_prob[j] * cov_prob[j]);
+            as_prob = w_rounded.data();
+            cov_prob = nullptr;
+        }
+    }
     OEM_TRY(create_store_layout(row_ptr, tid, as_prob, cov_prob, n_reads, nnz, n_txps, device, opts, s, relabel));
     StageTimer tm;
     // (the test-only library keeps the builders' streams when asked to: the layout tests hash them)

@@ -936,6 +936,47 @@ def test_full_size_c3_coverage_store_matches_oracle():
         assert binfo[0].niter == 6 and binfo[0].n_passes == 7
         assert_counts_close(bout[0], wantb, st.n_reads, st.n_txps, 1e-8, "c3 with coverage, batched bootstrap replicate")
         assert abs(bout[1].sum() - st.n_reads) < 1e-7 * st.n_reads
+    # opt-in weight_coding = 2: the static weight (p as f64) * cov rounded once to f32 (<= 6e-8 relative per weight),
+    # the store an f32 store (8 B per alignment, the kernels of `roofline.frac_coverage_f32w`) -- against the SAME
+    # strict-f64 oracle at 1e-6, and to convergence against the f64 store's run
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, st.n_txps, weight_coding=2) as d2:
+        _h, alg = d2.bytes()
+        assert alg == st.tid.size * 8 + (st.n_reads + 1) * 4 + 2 * st.n_txps * 8
+        cnt2, info2 = d2.em_run(None, 12, 0.0, 50)
+        assert info2.niter == 12 and info2.n_passes == 13
+        assert_counts_close(cnt2, want, st.n_reads, st.n_txps, 1e-6, "c3 with coverage, weights rounded to f32, 12 iterations")
+        assert abs(cnt2.sum() - st.n_reads) < 1e-7 * st.n_reads
+        full2, finfo2 = d2.em_run(None, 1000, 1e-3, 50)
+        assert abs(int(finfo2.niter) - int(finfo.niter)) <= 1 and finfo2.converged == finfo.converged
+        assert_counts_close(full2, full, st.n_reads, st.n_txps, RTOL, "c3 with coverage, weights rounded to f32, to the stop")
+
+
+def test_coverage_weights_rounded_to_f32_are_exactly_that():
+    """oem_store_opts.weight_coding = 2 changes ONE thing: the stored static weight is f32((p as f64) * cov).  The run
+    equals the oracle's on a store whose as_prob IS that rounded product (1e-10: only summation order differs), stays
+    within 1e-6 of the strict-f64 oracle, and without a coverage column the option is coding 0 (the lossless table)."""
+    st = synth.make_store(120_000, 5_000, 6.0, seed=29, coverage=True)
+    T = st.n_txps
+    w32 = (st.as_prob.astype(np.float64) * st.cov_prob).astype(np.float32)
+    o_rounded = c_oracle.Store(st.row_ptr, st.tid, w32, None, T)
+    o_strict = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T)
+    for gate, thresh, m in ((50, 1e-3, 1000), (1, 0.0, 40)):
+        with DeviceStore(st.row_ptr, st.tid, st.as_prob, st.cov_prob, T, weight_coding=2) as d:
+            assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) == 0
+            cnt, info = d.em_run(None, m, thresh, gate)
+            W = d.bootstrap_weights(3, 0)
+            bout, _ = d.bootstrap(1, row_w_all=W[None, :], max_iter=8, conv_thresh=0.0)
+        want, wi = c_oracle.do_em(o_rounded, max_iter=m, conv_thresh=thresh, min_iter_gate=gate)
+        assert (info.niter, info.converged) == (wi.niter, wi.converged)
+        assert_counts_close(cnt, want, st.n_reads, T, 1e-10, "rounded weights vs the oracle on the rounded weights")
+        strict, si = c_oracle.do_em(o_strict, max_iter=m, conv_thresh=thresh, min_iter_gate=gate)
+        if si.niter == info.niter:
+            assert_counts_close(cnt, strict, st.n_reads, T, 1e-6, "rounded weights vs the strict-f64 oracle")
+        wantb, _ = c_oracle.do_em(o_rounded, row_w=W, max_iter=8, conv_thresh=0.0)
+        assert_counts_close(bout[0], wantb, st.n_reads, T, 1e-10, "rounded weights, injected replicate")
+    plain = synth.make_store(50_000, 2_000, 6.0, seed=30)
+    with DeviceStore(plain.row_ptr, plain.tid, plain.as_prob, None, plain.n_txps, weight_coding=2) as d:
+        assert d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES) > 0     # no coverage column: coding 0
 
 
 @pytest.mark.timeout(900)
