@@ -28,11 +28,11 @@ LIB_PATH = os.path.join(HERE, "liboarfish_em.so")
 TESTING_LIB_PATH = os.path.join(HERE, "liboarfish_em_testing.so")
 
 # sources of the product library
-SOURCES = ["oem_api.hip", "oem_em_driver.hip", "oem_bootstrap.hip", "oem_cells.hip", "oem_timing.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_tile_pipe.hip", "oem_batch_kernels.hip",
+SOURCES = ["oem_api.hip", "oem_em_driver.hip", "oem_bootstrap.hip", "oem_cells.hip", "oem_timing.hip", "oem_kernels.hip", "oem_tile_kernels.hip", "oem_batch_kernels.hip",
            "oem_multi_kernels.hip", "oem_layout.cpp", "oem_layout_device.hip", "oem_layout_pack.hip", "oem_layout_dict.hip", "oem_coverage_device.hip",
            "oem_builder.cpp", "oem_comm.cpp", "oem_p2p.hip", "oem_knobs.cpp"]
 # the testing library swaps these for their -DOEM_TESTING build and adds the hooks
-TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip", "oem_tile_pipe.hip", "oem_batch_kernels.hip"]
+TESTING_VARIANTS = ["oem_comm.cpp", "oem_knobs.cpp", "oem_tile_kernels.hip", "oem_batch_kernels.hip"]
 TESTING_ONLY = ["oem_testing.hip"]
 HEADERS = ["oem_internal.h", "oem_driver.h", "oem_layout.h", "oem_tile_common.h", "oem_lane_runs.h", os.path.join(INCLUDE, "oarfish_em.h")]
 

@@ -198,7 +198,7 @@ int upload_tiled(oem_store *s, const TiledHost &h)
     OEM_TRY(upload_vec(&t.q_dst, h.q_dst, &s->hbm_bytes));
     OEM_TRY(upload_vec(&t.bucket_base, h.bucket_base, &s->hbm_bytes));
     t.h_bucket_base = h.bucket_base;
-    OEM_TRY(dev_alloc(&t.queue, h.n_remote + queue_slack(), &s->hbm_bytes)); // (test-only library: + the slack k_em_tile_p parks its idle register slots in)
+    OEM_TRY(dev_alloc(&t.queue, h.n_remote, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&t.row_w_perm, h.n_rows, &s->hbm_bytes));
     t.present = true;
     return OEM_OK;

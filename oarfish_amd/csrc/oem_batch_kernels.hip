@@ -89,18 +89,13 @@ constexpr int kFoldThreadsB = 1024;
 // pass; here 1 -> 2 | 4 copies took 6 % off the batched pass, profiles/r04_notes.md.)
 constexpr uint32_t kPoolE = 5888; // 46 KiB: theta + counts 46 + denominators 32 = 78 KiB per workgroup
 constexpr uint32_t kMaxCopyShiftE = 3;
-// Three workgroups per CU (test-only library, OEM_TILE_E_HALF=1 on a store cut into tiles of <= 512 reads,
-// OEM_TILE_ROWS=512): half the denominators, two register-resident records per thread, one slice per wavefront: theta +
-// counts 36 + denominators 16 = 52 KiB, 70 VGPRs.  Measured at C3 (profiles/r05_notes.md): the batched pass is 5 %
-// SLOWER than two workgroups on tiles of 1024 reads -- a tile's window (load, clear, flush) costs the same for half the
-// reads.  Not shipped.
-constexpr uint32_t kRowsHalfE = 512;
-constexpr uint32_t kPoolHalfE = 4608;
-static_assert(kPoolHalfE >= 2 * kWin * kEB, "theta and one copy of the widest window must fit");
+// (Three workgroups per CU on tiles of <= 512 reads -- half the denominators, 52 KiB, 70 VGPRs -- were built and measured
+// in round 5: the batched pass 5 % SLOWER, a tile's window costs the same for half the reads; removed in round 6.)
 template <uint32_t kRows> struct TileShapeE {
-    static constexpr uint32_t pool = kRows == kTileRows ? kPoolE : kPoolHalfE;
-    static constexpr int rem = kRows == kTileRows ? kRemE : 2;
-    static constexpr int min_waves = kRows == kTileRows ? 4 : 6;
+    static_assert(kRows == kTileRows, "one tile shape");
+    static constexpr uint32_t pool = kPoolE;
+    static constexpr int rem = kRemE;
+    static constexpr int min_waves = 4;
 };
 static_assert(kPoolE >= 2 * kWin * kEB, "theta and one copy of the widest window must fit");
 static_assert(kB % kEB == 0 && kE >= 1, "kBatch must be a multiple of the epoch width");
@@ -925,9 +920,6 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
     const uint64_t wsz = f64w ? 8 : 4;
     const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
     const bool nt = stream_bytes > (192ull << 20); // beyond the Infinity Cache: stream non-temporally
-#ifdef OEM_TESTING // (three workgroups per CU on tiles of <= 512 reads: measured slower, kept for the measurement)
-    const bool half = t.tile_rows <= kRowsHalfE && knob("OEM_TILE_E_HALF", 0) != 0;
-#endif
     const bool fused = !f64w && t.dict_fused && t.dict && t.r_wi && t.dict_n <= kDictE; // (no weight stream: see kFused)
 #define OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, FUSED)                                                            \
     hipLaunchKernelGGL((k_em_tile_e<NT, WT, PK, ROWS, FUSED>), dim3(t.n_tiles), dim3(kTileThreadsE), 0, bb.stream,      \
@@ -938,15 +930,7 @@ int launch_batch_pass(oem_store *s, const BatchBuffers &bb)
         if (sizeof(WT) == 4 && fused) OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, (sizeof(WT) == 4));                  \
         else OEM_LAUNCH_TILE_E4(NT, WT, W, RW, PK, ROWS, false);                                                      \
     } while (0)
-#ifdef OEM_TESTING
-#define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK)                                                                         \
-    do {                                                                                                              \
-        if (half) OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kRowsHalfE);                                                  \
-        else OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kTileRows);                                                        \
-    } while (0)
-#else
 #define OEM_LAUNCH_TILE_E2(NT, WT, W, RW, PK) OEM_LAUNCH_TILE_E3(NT, WT, W, RW, PK, kTileRows)
-#endif
 #define OEM_LAUNCH_TILE_E(NT, WT, W, RW)                                                                              \
     do {                                                                                                              \
         if (t.packed) OEM_LAUNCH_TILE_E2(NT, WT, W, RW, true);                                                        \

@@ -46,7 +46,6 @@ int fail(int code, const char *fmt, ...);
 // Tuning / test switch (oem_knobs.cpp): the product library always returns `dflt`; only the
 // test-only library built with -DOEM_TESTING reads the environment variable `name`.
 long knob(const char *name, long dflt);
-uint32_t queue_slack(); // oem_knobs.cpp: kQueueSlack in the test-only library, 0 in the product
 
 // ---------------------------------------------------------------------------
 // Device-resident loop state of one EM problem (em.rs:169-170 rel_diff, niter).
@@ -285,9 +284,6 @@ int launch_deferred_sweep(oem_store *s, double *prev, const double *cur, const D
 // the start of a deferred run in one launch: theta_0 filled (or left: init_abundances), the other vectors, slots, state zeroed
 int launch_deferred_init(oem_store *s, double *const bufs[3], double avg, bool fill);
 
-// oem_tile_pipe.hip: the same pass as a software pipeline over tiles (persistent workgroups), for the stores it applies to
-bool tile_pipeline_applies(const oem_store *s, const BatchState *problems);
-int launch_tile_pipeline(oem_store *s, const double *theta, double *cnt, const EmState *state, const uint32_t *row_w_perm, bool nt);
 
 // per-cell batches (oem_multi_kernels.hip)
 int launch_multi_init(oem_store *s, double *theta, const uint64_t *d_problem_reads, const MultiBuffers &mb);

@@ -22,15 +22,4 @@ long knob(const char *name, long dflt)
 #endif
 }
 
-// Slack entries behind a store's queue (oem_layout.h: kQueueSlack).  Their only user is the pipelined tile walk, which
-// exists in the test-only library alone: a product store -- every row shard, every per-cell group -- allocates none.
-uint32_t queue_slack()
-{
-#ifdef OEM_TESTING
-    return kQueueSlack;
-#else
-    return 0u;
-#endif
-}
-
 } // namespace oem

@@ -54,12 +54,6 @@ static_assert((kTileRows - 1) >> (32 - kPackRowShift) == 0, "the read index must
 
 constexpr uint32_t kTileSlices = kTileRows / 64;
 
-// Slack entries behind the queue's n_remote: the pipelined tile kernel (oem_tile_pipe.hip) stores a value for every
-// register slot of its remote records, and the slots a tile leaves empty write here -- one entry per wavefront of
-// the grid (ONE entry for all of them was a million stores per pass to one address: pass 0.146 -> 0.316 ms).
-constexpr uint32_t kPipeMaxGrid = 4096;
-constexpr uint32_t kQueueSlack = kPipeMaxGrid * 4;
-
 // Reads per tile by store size.  A pass over a small store is ONE round of workgroups and lasts as long as a tile
 // lives; a wavefront walks its slices one after another, so a 125 k-read store (the row shard of one of eight ranks
 // at 1 M reads) is 160 workgroups of four slices per wavefront on a chip with 1280 resident slots.  Cut into

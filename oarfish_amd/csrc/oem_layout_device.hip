@@ -650,7 +650,7 @@ int build_impl(oem_store *s, uint32_t problem_size, uint32_t win_cap, uint32_t t
     OEM_HIP(hipMemcpyAsync(t.h_bucket_base.data(), t.bucket_base, sizeof(uint32_t) * ((size_t)n_buckets + 1),
                            hipMemcpyDeviceToHost, st));
     OEM_HIP(hipStreamSynchronize(st));
-    OEM_TRY(out_alloc(&t.queue, n_remote + queue_slack(), &s->hbm_bytes)); // (test-only library: + the slack k_em_tile_p parks its idle register slots in)
+    OEM_TRY(out_alloc(&t.queue, n_remote, &s->hbm_bytes));
     OEM_TRY(out_alloc(&t.row_w_perm, n_rows, &s->hbm_bytes));
     t.n_tiles = n_tiles;
     t.win_cap = win_cap;

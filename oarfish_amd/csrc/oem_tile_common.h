@@ -1,5 +1,5 @@
-// oem_tile_common.h -- device helpers shared by the tile kernels (oem_tile_kernels.hip: one workgroup per tile;
-// oem_tile_pipe.hip: persistent workgroups walking tiles in a software pipeline).  SELL-64 slice registers, the
+// oem_tile_common.h -- device helpers of the tile kernel (oem_tile_kernels.hip: one workgroup per tile; round 5's
+// pipelined tile walk shared them -- measured slower, removed in round 6: HISTORY.md).  SELL-64 slice registers, the
 // weight codings of oem_layout_dict.hip, the per-slice fold (em.rs:97-131: denominator, then increments).
 #pragma once
 

@@ -615,12 +615,9 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     } while (0)
     // (a store whose codes carry the fused index has no other way to be read; the knob -- testing build, A/B --
     // switches only the byte-stream coding off)
-    const bool pipelined = !rd && tile_pipeline_applies(s, problems); // oem_tile_pipe.hip: measured, not shipped (test-only library)
-    if (pipelined) OEM_TRY(launch_tile_pipeline(s, theta, cnt, state, row_w_perm, nt));
     const bool coded = !f64w && t.dict_n > 0 && !t.dict_fused && knob("OEM_NO_DICT", 0) == 0;
     const bool bytes = coded && !t.dict_words, words = coded && t.dict_words;
-    if (pipelined) {
-    } else if (f64w) {
+    if (f64w) {
         if (nt) OEM_TILE(double, true, t.w64, t.r_w64, kWPlain);
         else OEM_TILE(double, false, t.w64, t.r_w64, kWPlain);
     } else if (words) {
@@ -717,7 +714,6 @@ int launch_permute_row_w(oem_store *s, const uint32_t *row_w, uint32_t *row_w_pe
 } // namespace oem
 
 #ifdef OEM_TESTING
-namespace oem { int pipe_probe_set(unsigned long long *d); } // oem_tile_pipe.hip
 // Test hook: one probed E/M pass (after an unprobed one); out = n_tiles x 16 wall-clock stamps (100 MHz).
 extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint64_t n_out)
 {
@@ -737,12 +733,10 @@ extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint6
     OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr));   // warm
     OEM_HIP(hipStreamSynchronize(s->stream));
     OEM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &d, sizeof(d)));
-    OEM_TRY(pipe_probe_set(d)); // (whichever of the two tile kernels the store takes)
     int rc = launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr);
     hipStreamSynchronize(s->stream);
     unsigned long long *null = nullptr;
     hipMemcpyToSymbol(HIP_SYMBOL(g_tile_probe), &null, sizeof(null));
-    pipe_probe_set(nullptr);
     if (rc == OEM_OK && hipMemcpy(out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(OEM_ERR_HIP, "oem_debug_tile_probe: read-back failed");
     hipFree(d);

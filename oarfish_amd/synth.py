@@ -116,8 +116,12 @@ def _chunk(c: int, n: int, seed: int, n_txps: int, kbar: float, cdf, g_start, g_
         order, pos = fam
         n_genes = len(order)
         ps = pos[g]
-        other = 3 * (ps // 3) + (ps % 3 + 1 + rng.integers(0, 2, size=tot)) % 3
-        g2 = order[np.minimum(other, n_genes - 1)]
+        # (the last family is incomplete when the gene count is no multiple of three: the index wraps inside the family's
+        # real size, so its reads still draw their far hit from ANOTHER gene -- a family of one has only itself)
+        fsize = np.minimum(3, n_genes - 3 * (ps // 3))
+        step = np.where(fsize == 3, 1 + rng.integers(0, 2, size=tot), 1)
+        other = 3 * (ps // 3) + (ps % 3 + step) % fsize
+        g2 = order[other]
         anywhere = g_start[g2] + (rng.random(tot) * g_size[g2]).astype(np.int64)
     t = np.where(is_gene, in_gene, anywhere)
     t[is_primary] = t0

@@ -143,14 +143,18 @@ def default_threads() -> int:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
+    def read(path):
+        with open(path) as f:
+            return f.read()
+
     try:   # cgroup v2: "quota period" or "max period"
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        q = read("/sys/fs/cgroup/cpu.max").split()
         if len(q) == 2 and q[0] != "max" and float(q[1]) > 0:
             n = min(n, max(1, int(float(q[0]) / float(q[1]) + 0.5)))
     except (OSError, ValueError):
         try:   # cgroup v1
-            quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = float(read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"))
+            period = float(read("/sys/fs/cgroup/cpu/cpu.cfs_period_us"))
             if quota > 0 and period > 0:
                 n = min(n, max(1, int(quota / period + 0.5)))
         except (OSError, ValueError):

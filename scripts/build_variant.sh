@@ -7,7 +7,7 @@ dir=$1; defs=$2
 cd "$(dirname "$0")/.."
 stale() {
   if [ -n "$OEM_AB_ALL" ]; then rm -f oarfish_amd/csrc/_obj/*.o
-  else rm -f oarfish_amd/csrc/_obj/oem_tile_pipe*.o oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o; fi
+  else rm -f oarfish_amd/csrc/_obj/oem_tile_kernels*.o oarfish_amd/csrc/_obj/oem_batch_kernels*.o oarfish_amd/csrc/_obj/oem_multi_kernels*.o; fi
 }
 stale
 OEM_EXTRA_DEFS="$defs" python -m oarfish_amd.build > /dev/null 2>&1

@@ -1,22 +1,19 @@
 """GPU tests of the variants of the batched bootstrap's tile kernel (k_em_tile_e, oem_batch_kernels.hip):
 the weight table of a store with <= 128 distinct weights read from the spare bits of the window codes (kFused, what a
-default store takes) against the f32 weight stream (oem_store_opts.weight_coding = 1), and the three-workgroups-per-CU
-kernel on tiles of <= 512 reads (test-only library, OEM_TILE_ROWS=512 + OEM_TILE_E_HALF=1; measured slower and not
-shipped, profiles/r05_notes.md).  Same semantics: em.rs:273-290 over resampled reads, per-replicate stopping."""
+default store takes) against the f32 weight stream (oem_store_opts.weight_coding = 1).  Same semantics: em.rs:273-290 over resampled reads, per-replicate stopping."""
 import numpy as np
 import pytest
 
 from oarfish_amd import _lib
 from oarfish_amd.types import DeviceStore
 from oracle import c_oracle
-from tests.common import assert_counts_close
-from tests.test_tile_pipe_gpu import _store
+from tests.common import assert_counts_close, tile_test_store as _store
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kind", ["dense", "sparse", "long", "remote", "ragged"])
-@pytest.mark.parametrize("variant", ["fused", "f32", "fused_half", "f32_half"])
+@pytest.mark.parametrize("variant", ["fused", "f32"])
 def test_batched_replicates_match_the_oracle_on_every_kernel_variant(kind, variant, monkeypatch):
     row_ptr, tid, p, T = _store(kind, seed=23)
     n_reads = len(row_ptr) - 1
@@ -24,10 +21,6 @@ def test_batched_replicates_match_the_oracle_on_every_kernel_variant(kind, varia
     n_rep = 5   # more replicates than slots: a slot is handed its next replicate while the others run on
     row_w = rng.multinomial(n_reads, np.full(n_reads, 1.0 / n_reads), size=n_rep).astype(np.uint32)
     o = c_oracle.Store(row_ptr, tid, p, None, T)
-    half = variant.endswith("_half")
-    if half:
-        monkeypatch.setenv("OEM_TILE_ROWS", "512")
-        monkeypatch.setenv("OEM_TILE_E_HALF", "1")
     wc = 1 if variant.startswith("f32") else 0
     with _lib.testing(), DeviceStore(row_ptr, tid, p, None, T, weight_coding=wc) as d:
         n_dict = d.info(_lib.OEM_INFO_WEIGHT_DICT_ENTRIES)
