@@ -11,7 +11,7 @@ wl=${2:-c3}
 out=gpurun_out/profiles
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --no-f32-compare --no-live-traffic --bootstraps 0 --cells 0"
+B="python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --no-f32-compare --no-live-traffic --no-side-legs --bootstraps 0 --cells 0"
 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o $tag -- $B > $out/${tag}_bench_under_rocprof.json 2> $out/kt.err
 cp $out/kt/${tag}_kernel_stats.csv $out/${tag}_kernel_stats.csv 2>/dev/null
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pf -o $tag -- $B > /dev/null 2> $out/pf.err

@@ -41,6 +41,16 @@ cp $out/pmc_cells/summary.txt $out/r06_c5_cells625_pmc_summary.txt
 # recurring far alignments (paralog families): kernel stats of the same pass
 KT_TOP=4 bash scripts/kt.sh $out/paralog python scripts/pass_time.py c3 paralog > $out/paralog.log 2>&1
 cp $out/paralog/kernel_stats.csv $out/r06_c3_paralog_kernel_stats.csv
+# configs[1]: kernel stats of the same pass on the 1 M-read store, its loop trace, and the bench line of the C2 workload
+KT_TOP=4 bash scripts/kt.sh $out/c2 python scripts/pass_time.py c2 > $out/c2.log 2>&1
+cp $out/c2/kernel_stats.csv $out/r06_c2_kernel_stats.csv
+bash scripts/loop_trace.sh $out/lt_c2 c2 200 20 > $out/r06_c2_loop_trace.txt 2>&1
+python bench.py --workload c2 --steps 1000 --warmup 50 --bootstraps 0 --cells 0 --no-live-traffic --no-cpu-baseline 2> /dev/null | tail -1 > $out/r06_bench_c2.json
+# in-kernel phase stamps (test-only library): where a tile's life goes, per phase (the stall-site account: no ATT decoder
+# and no PC sampling on this image)
+python scripts/tile_probe.py c3 2>/dev/null | grep -v amdgpu > $out/r06_tile_probe.txt
+python scripts/tile_e_probe.py c3 2>/dev/null | grep -v amdgpu > $out/r06_tile_e_probe.txt
+python scripts/shard_compute_time.py 2>/dev/null | grep "^N=" > $out/r06_shard_compute_time.txt
 # gpurun copies back at most 64 MiB: the raw traces and counter tables stay on the box, the summaries travel
 find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete
 du -sh gpurun_out | tail -1
