@@ -228,10 +228,10 @@ def kernel_source_sha():
 
 def hbm_traffic(workload):
     """HBM bytes of one pass from the rocprofv3 PMC passes of this same command (collected by
-    scripts/collect_r05.sh; FETCH_SIZE corrected by the calibration recorded beside it).  The counters are not
+    scripts/collect_r06.sh; FETCH_SIZE corrected by the calibration recorded beside it).  The counters are not
     collected inside the run, so the file names the kernel sources it was measured on: `stale` says whether they have
     changed since."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
         if os.path.exists(tj):
             j = json.load(open(tj))
@@ -751,7 +751,7 @@ def bootstrap_leg(args, cfg, full, store, dist_mode, rank, world, local_rank, sy
                 ach = nbytes / (ms * 1e-3) / 1e9
                 traffic, tsrc = None, None
                 tj = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_boot_hbm_traffic.json")
-                                      for tag in ("r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
+                                      for tag in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
                 tstale = None
                 if tj:   # PMC passes of the same kernels (scripts/collect_pmc_cmd.sh on scripts/boot_passes.py)
                     j = json.load(open(tj))
@@ -796,7 +796,7 @@ def cells_traffic(n_cells, per_cell, T):
     (scripts/collect_cells_traffic.sh -> profiles/r0N_c5_cells625_hbm_traffic.json), when the leg is that slice."""
     if (n_cells, per_cell, T) != (625, 50_000, 60_000):
         return None, None
-    for tag in ("r05", "r04"):
+    for tag in ("r06", "r05", "r04"):
         q = os.path.join(ROOT, "profiles", f"{tag}_c5_cells625_hbm_traffic.json")
         if os.path.exists(q):
             try:
