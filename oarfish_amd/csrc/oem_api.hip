@@ -145,7 +145,7 @@ void free_store(oem_store *s)
         oem::BatchBuffers &b = s->batch[c];
         if (c > 0 && b.stream) { hipStreamSynchronize(b.stream); hipStreamDestroy(b.stream); }
         hipFree(b.d_row_w);
-        hipFree(b.theta); hipFree(b.cnt); hipFree(b.out); hipFree(b.queue); hipFree(b.state);
+        hipFree(b.theta); hipFree(b.cnt); hipFree(b.out); hipFree(b.queue); hipFree(b.state); hipFree(b.rel_slots);
         hipFree(b.row_w); hipFree(b.overflow);
         if (b.h_state) hipHostFree(b.h_state);
         if (b.h_out) hipHostFree(b.h_out);

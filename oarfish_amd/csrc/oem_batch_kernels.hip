@@ -775,7 +775,8 @@ __global__ __launch_bounds__(kFoldThreadsB) void k_remote_fold_b(
 // rel-diff / swap / clear / state machine for kB slots (em.rs:194-218, :238-254); curr_b[t] = cnt[t][b]
 constexpr int kRelB = 1024; // as k_reldiff_swap_clear: few fat workgroups, the state-line atomics serialise
 __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta, double *__restrict__ cnt,
-                                                   double *__restrict__ out, BatchState *st, EmParams p)
+                                                   double *__restrict__ out, BatchState *st, EmParams p,
+                                                   unsigned long long *rel_slots)
 {
     uint32_t running = 0, final_ = 0; // SGPR masks
 #pragma unroll
@@ -825,11 +826,14 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
     __syncthreads();
     __shared__ bool is_last;
     if (threadIdx.x == 0) {
+        // the workgroup's maxima go to ITS row of the slot table (kBatchRelSlots rows of kB words): ~200 workgroups x kB
+        // atomics on the four state words were ~1000 read-modify-writes on one line, performed one after another
+        unsigned long long *row = rel_slots + (size_t)(blockIdx.x & (kBatchRelSlots - 1u)) * kB;
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
             double m = smax[0][b];
             for (int i = 1; i < kRelB / 64; ++i) m = fmax(m, smax[i][b]);
-            if (m > 0.0) atomicMax(&st[b].rel_bits, (unsigned long long)__double_as_longlong(m));
+            if (m > 0.0) atomicMax(&row[b], (unsigned long long)__double_as_longlong(m));
         }
         // (ordering of the maxima against the ticket: see k_reldiff_swap_clear, oem_kernels.hip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -837,6 +841,19 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
         is_last = (ticket == gridDim.x - 1);
     }
     __syncthreads();
+    __shared__ unsigned long long slot_max[kB];
+    if (is_last) { // (workgroup-uniform) the table's maximum per slot, the table zeroed for the next pass
+        static_assert(kBatchRelSlots * kB <= kRelB && kB <= 64, "one table word per thread");
+        unsigned long long bits = 0ull;
+        if (threadIdx.x < kBatchRelSlots * kB) {
+            bits = __hip_atomic_load(&rel_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rel_slots[threadIdx.x] = 0ull;
+        }
+        if (threadIdx.x < kB) slot_max[threadIdx.x] = 0ull;
+        __syncthreads();
+        if (bits) atomicMax(&slot_max[threadIdx.x % kB], bits); // (LDS; word w of the table belongs to slot w mod kB)
+        __syncthreads();
+    }
     if (is_last && threadIdx.x == 0) {
 #pragma unroll
         for (int b = 0; b < kB; ++b) {
@@ -846,9 +863,7 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
                 continue;
             }
             if (!((running >> b) & 1u)) continue;
-            const unsigned long long bits =
-                __hip_atomic_load(&st[b].rel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double rel_diff = __longlong_as_double((long long)bits);
+            const double rel_diff = __longlong_as_double((long long)slot_max[b]);
             st[b].last_rel = rel_diff;
             st[b].n_passes += 1;
             uint32_t niter = st[b].niter;
@@ -860,7 +875,6 @@ __global__ __launch_bounds__(kRelB) void k_reldiff_b(double *__restrict__ theta,
                 st[b].niter = niter;
                 if (niter >= p.max_iter) st[b].phase = kPhaseFinal;    // em.rs:181
             }
-            st[b].rel_bits = 0ull;
         }
         st[0].blocks_arrived = 0u;
     }
@@ -977,7 +991,7 @@ int launch_batch_reldiff(oem_store *s, const BatchBuffers &bb, EmParams p)
 {
     // the sweep moves kB times the bytes of k_reldiff_swap_clear: 256 workgroups (97 -> ~30 us at 200 k transcripts)
     const int grid = grid_for(p.n_txps, kRelB, 256);
-    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, bb.stream, bb.theta, bb.cnt, bb.out, bb.state, p);
+    hipLaunchKernelGGL(k_reldiff_b, dim3(grid), dim3(kRelB), 0, bb.stream, bb.theta, bb.cnt, bb.out, bb.state, p, bb.rel_slots);
     OEM_HIP(hipGetLastError());
     return OEM_OK;
 }

@@ -24,6 +24,8 @@ int ensure_batch(oem_store *s, int chain)
     OEM_TRY(dev_alloc(&b.out, T * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.queue, (size_t)s->tiled.n_remote * kBatch, &s->hbm_bytes));
     OEM_TRY(dev_alloc(&b.state, kBatch, &s->hbm_bytes));
+    OEM_TRY(dev_alloc(&b.rel_slots, (size_t)kBatchRelSlots * kBatch, &s->hbm_bytes));
+    OEM_HIP(hipMemsetAsync(b.rel_slots, 0, sizeof(unsigned long long) * kBatchRelSlots * kBatch, b.stream));
     OEM_TRY(dev_alloc(&b.row_w, (size_t)s->tiled.n_rows * kBatch + 16, &s->hbm_bytes));
     OEM_HIP(hipMemsetAsync(b.row_w, 0, (size_t)s->tiled.n_rows * kBatch + 16, b.stream));
     // a slot that is never handed a replicate (n_boot < kBatch, the tail of a chain) is still swept by the

@@ -166,6 +166,9 @@ struct BatchState {
 };
 static_assert(sizeof(BatchState) == 48, "BatchState layout");
 
+// k_reldiff_b keeps its workgroups' maxima in kBatchRelSlots x kBatch words, not in the slots' four state words: ~200
+// workgroups x 4 atomics on ONE line ran at the rate of one hot address (0.08 G/s: 12 of the kernel's 16 us).
+constexpr uint32_t kBatchRelSlots = 32;
 struct BatchBuffers {
     hipStream_t stream = nullptr; // the chain's own stream (chain 0: the store's)
     uint32_t *d_row_w = nullptr;  // n_reads u32: the replicate being handed to a slot, caller order
@@ -174,6 +177,7 @@ struct BatchBuffers {
     double *out = nullptr;     // [kBatch][T]
     double *queue = nullptr;   // [n_remote][kBatch]
     BatchState *state = nullptr;
+    unsigned long long *rel_slots = nullptr; // [kBatchRelSlots][kBatch] running maxima of k_reldiff_b (zero between passes)
     uint8_t *row_w = nullptr;  // [rows][kBatch], tile order: one byte per slot
     uint32_t *overflow = nullptr;
     BatchState *h_state = nullptr; // pinned
