@@ -1700,3 +1700,20 @@ def test_stopping_rule_one_pass_behind_stops_where_the_reference_stops(far, monk
         assert_counts_close(cnt, ccnt, st.n_reads, T, 1e-10, "one pass behind vs the classic loop, " + what)
     assert again[1].niter == got[0][1].niter
     assert_counts_close(again[0], got[0][0], st.n_reads, T, 1e-12, "second run")
+
+
+def test_last_iteration_decided_by_the_sweep_on_a_wide_annotation():
+    """k_deferred_sweep (oem_tile_kernels.hip) caps its grid at 256 workgroups x 1024 transcripts per trip: an annotation
+    of 700 k transcripts takes several trips per workgroup.  Runs that end at max_iter -- the sweep decides, converged or
+    not -- against the oracle: iteration count, convergence flag, rel_diff, counts."""
+    st = synth.make_store(60_000, 700_000, 4.0, seed=77)
+    T = st.n_txps
+    o = c_oracle.Store(st.row_ptr, st.tid, st.as_prob, None, T)
+    with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, T) as d:
+        for m, th, g in ((1, 1e-3, 1), (2, 0.5, 1), (7, 0.0, 50), (52, 1.0, 50), (60, 1e-3, 50)):
+            cnt, info = d.em_run(None, m, th, g)
+            want, wi = c_oracle.do_em(o, max_iter=m, conv_thresh=th, min_iter_gate=g)
+            what = f"max_iter {m}, thresh {th}, gate {g}"
+            assert (info.niter, info.n_passes, info.converged) == (wi.niter, wi.n_passes, wi.converged), what
+            assert abs(info.rel_diff - wi.rel_diff) <= 1e-9 * max(abs(wi.rel_diff), 1e-12) + 1e-15, what
+            assert_counts_close(cnt, want, st.n_reads, T, 1e-9, what)
