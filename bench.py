@@ -613,7 +613,7 @@ def c2_leg(local_rank, sync):
     iterations (max_iter 1000, threshold 0: SURVEY 8a note 3) through oem_em_run -- wall time of the whole call, result
     copied out -- plus the HIP-event-timed pass and loop iteration and the pass's fraction of the HBM peak (the store's
     69 MB fit the Infinity Cache: a fraction above 1 would be possible here and is far away)."""
-    from oarfish_amd import synth
+    from oarfish_amd import _lib, synth
     from oarfish_amd.types import DeviceStore
     cfg = WORKLOADS["c2"]
     st = synth.make_store(cfg["n_reads"], cfg["n_txps"], cfg["kbar"], threads=max(2, min(32, os.cpu_count() or 8)))
@@ -633,14 +633,9 @@ def c2_leg(local_rank, sync):
         return dict(workload=cfg["name"], value=1000 / best, unit="EM iterations/s", iterations=int(info.niter),
                     n_passes=int(info.n_passes), em_run_seconds=best, kernel_avg_ms=pass_ms, device_ms_per_step=it_ms,
                     algorithmic_bytes_per_launch=alg, frac=alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    alignments=int(st.tid.size), tiles=d.info(_lib_const("OEM_INFO_TILES")),
+                    alignments=int(st.tid.size), tiles=d.info(_lib.OEM_INFO_TILES),
                     note="value = 1000 iterations / wall time of one oem_em_run call (best of 3), counts copied out; "
                          "kernel_avg_ms = one E/M pass (HIP events, best of 3 x 200 launches)")
-
-
-def _lib_const(name):
-    from oarfish_amd import _lib
-    return getattr(_lib, name)
 
 
 def shard_leg(full, cfg, n, local_rank):

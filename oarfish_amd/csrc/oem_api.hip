@@ -599,6 +599,9 @@ extern "C" int oem_store_create(const uint64_t *row_ptr, const uint32_t *tid, co
     if (!row_ptr) return fail(OEM_ERR_ARG, "oem_store_create: row_ptr is NULL");
     if (nnz > 0 && (!tid || !as_prob)) return fail(OEM_ERR_ARG, "oem_store_create: tid/as_prob is NULL");
     if (n_txps == 0) return fail(OEM_ERR_ARG, "oem_store_create: n_txps is 0");
+    if (opts && opts->weight_coding > 2) return fail(OEM_ERR_ARG, "oem_store_create: weight_coding %u (0, 1 or 2)", opts->weight_coding);
+    if (opts && opts->layout_build > 1) return fail(OEM_ERR_ARG, "oem_store_create: layout_build %u (0 or 1)", opts->layout_build);
+    if (opts && opts->reorder_rows > 2) return fail(OEM_ERR_ARG, "oem_store_create: reorder_rows %u (0, 1 or 2)", opts->reorder_rows);
     StageTimer tm;
     OEM_TRY(validate_csr(row_ptr, tid, n_reads, nnz, n_txps));
     std::vector<double> cov_fixed;

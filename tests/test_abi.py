@@ -50,6 +50,13 @@ def test_argument_validation_precedes_device_use():
     assert rc == _lib.OEM_ERR_ARG
     assert L.oem_em_run(None, None, 10, 1e-3, 50, None, None) == _lib.OEM_ERR_ARG
     assert L.oem_comm_create(None, 3, 2, 0, C.byref(h)) == _lib.OEM_ERR_ARG
+    # option words outside their documented values are refused, not read as some other value
+    tid = np.array([0, 1], dtype=np.uint32)
+    for field, bad in (("weight_coding", 3), ("layout_build", 2), ("reorder_rows", 3)):
+        o = _lib.StoreOptsC()
+        setattr(o, field, bad)
+        rc = L.oem_store_create(rp.ctypes.data, tid.ctypes.data, p.ctypes.data, None, 2, 2, 2, 0, C.byref(o), C.byref(h))
+        assert rc == _lib.OEM_ERR_ARG and field.encode() in L.oem_last_error(), field
 
 
 def test_fails_loudly_without_a_device():
