@@ -16,6 +16,12 @@
 namespace oem {
 namespace {
 
+#ifndef OEM_CELLS_HEAD_DIV
+#define OEM_CELLS_HEAD_DIV 4 // a large single group is split head : rest = 1 : (div - 1); 0 = not split
+#endif
+constexpr uint32_t kCellsHeadDiv = OEM_CELLS_HEAD_DIV;
+
+
 // What the last oem_em_run_cells call of this thread spent in its batched EM loops (HIP events on the
 // group's stream around the loop), for oem_cells_last_timing.
 thread_local double t_cells_loop_ms = 0.0;
@@ -355,6 +361,20 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         }
         groups.emplace_back(c0, c1);
         c0 = c1;
+    }
+    // One large group only (BASELINE configs[4]'s slice of one GPU: 625 cells, 250 M alignments, 2 GB of caller arrays):
+    // a quarter of the cells is cut off as a group of its own, so that the second worker uploads and lays out the rest
+    // under the head's EM loop instead of the device idling through the whole upload and layout build (~70 ms of a
+    // 0.67 s call).  Measured (scripts/cells_groups_exp.sh, three rounds): heads of 40 / 80 / 160 / 312 of 625 cells
+    // +7 / -0.5 / -3.4 / -0.5 % against one group -- a small head's own loop runs its few tiles badly, two halves just
+    // share the device.
+    if (groups.size() == 1 && n_cells >= 64 && nnz >= (64ull << 20)) {
+        const long head = knob("OEM_CELLS_HEAD", (long)(kCellsHeadDiv ? n_cells / kCellsHeadDiv : 0));
+        if (head >= 2 && (uint32_t)head + 2 <= n_cells) {
+            groups.clear();
+            groups.emplace_back(0u, (uint32_t)head);
+            groups.emplace_back((uint32_t)head, n_cells);
+        }
     }
     // Groups are independent runs.  With several of them two host threads draw groups from one counter, each group
     // on its own stream: one group's upload, layout build and read-back run under the other's EM loop, and the tail

@@ -1,1 +1,4 @@
-for rep in 1 2; do echo "== default (1 group)"; OEM_USE_TESTING_LIB=1 OEM_VERBOSE=1 python scripts/cells_bench.py 625 50000 60000 2>&1 | grep -v "amdgpu.ids" | grep "cells:\|batched" | tail -12; echo "== 2 groups"; OEM_USE_TESTING_LIB=1 OEM_CELLS_GROUP_NNZ=130000000 OEM_VERBOSE=1 python scripts/cells_bench.py 625 50000 60000 2>&1 | grep "cells:\|batched" | tail -14; echo "== 3 groups"; OEM_USE_TESTING_LIB=1 OEM_CELLS_GROUP_NNZ=90000000 python scripts/cells_bench.py 625 50000 60000 2>&1 | grep "batched" | tail -2;  echo "== 4 groups"; OEM_USE_TESTING_LIB=1 OEM_CELLS_GROUP_NNZ=65000000 python scripts/cells_bench.py 625 50000 60000 2>&1 | grep "batched" | tail -2; done
+#!/bin/bash
+# Runs ON THE GPU BOX: the 625-cell slice with a head of the cells cut off as a group of its own (test-only library,
+# OEM_CELLS_HEAD = cells in the head; 0 = one group), so that the rest uploads under the head's EM loop.
+for rep in 1 2 3; do for h in 0 40 80 160 312; do echo -n "head $h: "; OEM_USE_TESTING_LIB=1 OEM_CELLS_HEAD=$h python scripts/cells_bench.py 625 50000 60000 2>&1 | grep "batched" | tail -1; done; done
