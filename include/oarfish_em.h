@@ -401,7 +401,9 @@ int oem_time_allreduce(oem_store *store, uint32_t n_calls, float *out_avg_us);
 
 /* Device time of the batched EM loops of this thread's LAST oem_em_run_cells call: milliseconds between
  * HIP events recorded on the group's stream right before the first and right after the last pass of
- * every batched group (upload, layout build and read-back excluded), and the batched passes launched.
+ * every batched group (upload, layout build and read-back excluded) -- groups that ran side by side on the
+ * device (two workers) count the time they shared once: the length of the union of the groups' loops -- and
+ * the batched passes launched, summed over the groups.
  * Together with the per-cell n_passes of `infos` this gives bench.py the roofline of the per-cell leg:
  * bytes = sum over cells of n_passes * (nnz_c * 8 + (R_c + 1) * 4 + 2 * T * 8).  Zero when every group
  * took the cell-by-cell fallback. */

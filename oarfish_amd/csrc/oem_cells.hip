@@ -30,8 +30,26 @@ thread_local uint64_t t_cells_batched_passes = 0;
 // and the calling thread copies them into its thread-local pair at the end)
 struct CellsTiming {
     std::mutex mu;
-    double loop_ms = 0.0;
+    std::vector<std::pair<double, double>> loops; // [begin, end) of every group's EM loop, ms on the host's steady clock
     uint64_t passes = 0;
+    // Time during which at least one group's loop ran: groups of one call overlap on the device (two workers), and
+    // the sum of their durations would count the shared time twice.
+    double loop_ms()
+    {
+        std::sort(loops.begin(), loops.end());
+        double total = 0.0, cur_b = 0.0, cur_e = -1.0;
+        for (const auto &iv : loops) {
+            if (cur_e < cur_b || iv.first > cur_e) {
+                if (cur_e > cur_b) total += cur_e - cur_b;
+                cur_b = iv.first;
+                cur_e = iv.second;
+            } else if (iv.second > cur_e) {
+                cur_e = iv.second;
+            }
+        }
+        if (cur_e > cur_b) total += cur_e - cur_b;
+        return total;
+    }
 };
 thread_local CellsTiming *t_timing = nullptr;
 
@@ -160,9 +178,10 @@ int run_cells_batched(const uint64_t *cell_row_off, uint32_t n_cells, const uint
             if (rc2 == OEM_OK && hipEventRecord(ev1, s->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
-                    if (t_timing) {
+                    if (t_timing) { // the loop ended just now and lasted `ms` on the device
+                        const double end = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
                         std::lock_guard<std::mutex> lk(t_timing->mu);
-                        t_timing->loop_ms += ms;
+                        t_timing->loops.emplace_back(end - (double)ms, end);
                         t_timing->passes += launched;
                     }
                 }
@@ -428,7 +447,7 @@ extern "C" int oem_em_run_cells(const uint64_t *cell_row_off, uint32_t n_cells, 
         work(0);
     }
     tm_all.lap("cells: all groups");
-    t_cells_loop_ms = timing.loop_ms;
+    t_cells_loop_ms = timing.loop_ms();
     t_cells_batched_passes = timing.passes;
     for (int wk = 0; wk < kMaxWorkers; ++wk)
         if (rcs[wk] != OEM_OK) return fail(rcs[wk], "%s", errs[wk].c_str());
