@@ -98,6 +98,40 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     // last compacted the list, in tile order -- n_tiles is then the length of that list, and the grid follows it,
     // so a pass costs what its live cells cost (oem_multi_kernels.hip: k_multi_compact).
     uint32_t tile_index = blockIdx.x;
+    // The rel-diff of the PREVIOUS iteration rides along (DeferredRelDiff, oem_internal.h) on workgroups of its own, the
+    // LAST kRdBlocks of the grid: theta_{i-1} (`rd_prev`) against theta_i (what this pass reads as theta), their share of
+    // the transcripts each, theta_{i-1} zeroed (it is the accumulator of pass i + 1: em.rs:207).  Dispatched behind
+    // the last tile, they run in the slots the tile kernel's tail leaves idle.  (Rounds 5-6 gave every tile workgroup
+    // a share, requested with its theta window and looked at behind its first barrier: 1.5-2 us of a 141 us iteration
+    // at 10 M reads, 0.9 of 27.5 us at 1 M -- two more loads in front of every tile's records, and wave 0 late for
+    // the second barrier.)  A workgroup must look at `done` BEFORE it zeroes anything: run_em_deferred.
+    if (!problems && blockIdx.x >= n_tiles) {
+        if (!rd_prev || (state && state->done)) return;
+        const uint32_t rb = blockIdx.x - n_tiles;
+        const uint32_t i0 = rb * rd_chunk, i1 = i0 + rd_chunk < n_txps ? i0 + rd_chunk : n_txps;
+        double rel = 0.0;                                          // em.rs:194-201 (signed, floored at 0 by the maximum)
+        for (uint32_t ib = i0 + threadIdx.x; ib < i1; ib += 4 * kTileThreads) {
+            double pv[4], cv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { // (eight loads in flight before the first use)
+                const uint32_t i = ib + k * kTileThreads, ic = i < i1 ? i : ib;
+                pv[k] = rd_prev[ic];
+                cv[k] = theta[ic];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = ib + k * kTileThreads;
+                if (i < i1) {
+                    if (pv[k] > OEM_MIN_READ_THRESH) rel = fmax(rel, (cv[k] - pv[k]) / pv[k]);
+                    rd_prev[i] = 0.0;
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+        if ((threadIdx.x & 63u) == 0 && rel > 0.0) // (non-negative doubles order like their bit patterns; no return value: nothing waits)
+            atomicMax(&rd_slots[(rb * (kTileThreads / 64) + (threadIdx.x >> 6)) & (kRelSlots - 1u)], (unsigned long long)__double_as_longlong(rel));
+        return;
+    }
     if (problems) {
         tile_index = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
         if (tile_index >= n_tiles) return;
@@ -179,16 +213,6 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint32_t i = tx + u * kTileThreads;
         tw[u] = theta[td.lo + (i < td.win_len ? i : 0u)];
-    }
-    // The rel-diff of the PREVIOUS iteration rides along (DeferredRelDiff, oem_internal.h): this workgroup's share of
-    // the transcripts, theta_{i-1} against theta_i = what this pass reads as theta.  Requested with the window, looked
-    // at behind the first barrier: its atomic is long performed when the workgroup ends (at the end of the kernel it
-    // kept every workgroup alive for its round trip: +3 us per pass).
-    double rd_p = 0.0, rd_c = 0.0;
-    const uint32_t rd_i0 = blockIdx.x * rd_chunk, rd_i1 = rd_i0 + rd_chunk < n_txps ? rd_i0 + rd_chunk : n_txps;
-    if (rd_prev && rd_i0 + tx < rd_i1) {
-        rd_p = rd_prev[rd_i0 + tx];
-        rd_c = theta[rd_i0 + tx];
     }
     constexpr uint32_t kDictPer = (dict_entries<kDict>() + kTileThreads - 1) / kTileThreads;
     float dict_v[kDictPer];
@@ -282,21 +306,6 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_em_tile(
     __syncthreads();
     OEM_PROBE(3);
     OEM_EXIT_AT(128u);
-    if (rd_prev && rd_i0 < rd_i1 && (tx & ~63u) < rd_i1 - rd_i0) { // wave-uniform: the wavefronts that hold a share.
-        double rel = 0.0;                                          // em.rs:194-201 (signed, floored at 0 by the maximum),
-        if (rd_i0 + tx < rd_i1) {                                  // :207 for the buffer that rests
-            if (rd_p > OEM_MIN_READ_THRESH) rel = fmax(rel, (rd_c - rd_p) / rd_p);
-            rd_prev[rd_i0 + tx] = 0.0;
-        }
-        for (uint32_t i = rd_i0 + tx + kTileThreads; i < rd_i1; i += kTileThreads) { // (more transcripts than tiles x 256)
-            const double pv = rd_prev[i], cv = theta[i];
-            if (pv > OEM_MIN_READ_THRESH) rel = fmax(rel, (cv - pv) / pv);
-            rd_prev[i] = 0.0;
-        }
-        for (int off = 32; off > 0; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
-        if (lane == 0 && rel > 0.0) // (non-negative doubles order like their bit patterns; no return value: nothing waits)
-            atomicMax(&rd_slots[blockIdx.x & (kRelSlots - 1u)], (unsigned long long)__double_as_longlong(rel));
-    }
 
     // ---- remote alignments, phase A: denominators --------------------------------
     if (kRemIdx) {
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(256) void k_permute_row_w(const uint32_t *__restric
 // weights, two for the wide window), 8 local and 6 remote alignments per thread in registers; 4 to 8 interleaved
 // count-window copies for the narrow window cap (by the tile's window), one for the wide cap of sparse stores
 // (40 KiB LDS; same-address atomics are rare when few reads share a transcript).
+constexpr uint32_t kRdBlocks = 64; // workgroups of the deferred rel-diff behind a pass's tiles (k_em_tile)
 template <typename WT, bool kNT, bool kPacked, int kDict>
 static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *theta, double *cnt,
                         const EmState *state, const uint32_t *row_w_perm, const BatchState *problems, const DeferredRelDiff *rd)
@@ -555,14 +565,16 @@ static void launch_tile(oem_store *s, const WT *w, const WT *r_w, const double *
     const uint32_t grid = problems ? (n_tiles + 7u) / 8u * 8u : n_tiles; // (per-cell batch: see the tile index in k_em_tile)
     double *rd_prev = rd && !problems ? rd->prev : nullptr;
     unsigned long long *rd_slots = rd ? rd->slots : nullptr;
-    const uint32_t n_txps = s->csr.n_txps, rd_chunk = (n_txps + grid - 1) / grid;
+    // (the deferred rel-diff: kRdBlocks more workgroups behind the tiles', a share of the transcripts each)
+    const uint32_t n_rd = rd_prev ? kRdBlocks : 0u;
+    const uint32_t n_txps = s->csr.n_txps, rd_chunk = n_rd ? (n_txps + n_rd - 1) / n_rd : 0u;
     if (t.win_cap > kWin)
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, (sizeof(WT) == 4 ? OEM_WAVES_WIDE : 2), 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, (sizeof(WT) == 4 ? OEM_WAVES_WIDE : 2), 1, kNT, kWinWideLds, kPacked, kDict, (sizeof(WT) == 4 ? OEM_SETS_WIDE : 2)>), dim3(grid + n_rd), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles,
                            rd_prev, rd_slots, rd_chunk, n_txps);
     else
-        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), OEM_COPIES, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid), dim3(256), 0, s->stream,
+        hipLaunchKernelGGL((k_em_tile<WT, 8, 6, 256, tile_min_waves<WT, kDict>(), OEM_COPIES, kNT, kWin, kPacked, kDict, tile_sets<WT, kDict>()>), dim3(grid + n_rd), dim3(256), 0, s->stream,
                            t.tiles, t.codes, w, r_a, r_w, t.r_row, t.sd, t.queue, theta, cnt, state,
                            row_w_perm, problems, t.problem_size, n_tiles, t.widx, t.i_base, t.dict, t.r_wi, live_tiles,
                            rd_prev, rd_slots, rd_chunk, n_txps);
