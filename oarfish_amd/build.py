@@ -104,7 +104,8 @@ def _compile(src: str, testing: bool, verbose: bool) -> None:
 
 
 TESTING_HOOKS = ["oem_debug_layout_hash", "oem_debug_local_comm_create", "oem_test_reldiff_stress", "oem_debug_knob",
-                 "oem_debug_tile_probe", "oem_debug_tile_e_probe_begin", "oem_debug_tile_e_probe_end"]
+                 "oem_debug_tile_probe", "oem_debug_tile_e_probe_begin", "oem_debug_tile_e_probe_end",
+                 "oem_debug_overlap_probe"]
 
 
 def header_symbols() -> list:

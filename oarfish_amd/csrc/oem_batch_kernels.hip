@@ -73,6 +73,9 @@ __device__ unsigned int g_tile_e_exp = 0;
 #ifndef OEM_E_WR_GROUP
 #define OEM_E_WR_GROUP 1 // alignments whose LDS atomics are issued together in pass 2
 #endif
+#ifndef OEM_E_QUEUE_SC
+#define OEM_E_QUEUE_SC 0 // a queue piece's stores: 0 non-temporal, 1 `sc1`, 2 `sc0 sc1` (write-through: the line leaves the L2), 3 plain
+#endif
 constexpr int kB = kBatch;
 constexpr int kEB = 4;             // slots per epoch
 constexpr int kE = kB / kEB;       // epochs per pass
@@ -126,6 +129,27 @@ __device__ __forceinline__ uint32_t code_widx_b(uint32_t c, int h) // (see code_
 {
     const uint32_t r = h ? ((c >> 26) | (c << 6)) : ((c >> 10) | (c << 22));
     return (r >> 2) & 0x7fu;
+}
+
+// The 32-byte queue piece of a remote record (its four slots).  Non-temporal stores keep the line in the XCD's L2
+// until it is evicted; `sc1` stores write through and drop it (MI355X_MICROARCH.md, "stores of each flavour").
+__device__ __forceinline__ void store_queue_piece(double *qp, const double (&qv)[4])
+{
+#if OEM_E_QUEUE_SC == 1 || OEM_E_QUEUE_SC == 2
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t lo = {qv[0], qv[1]}, hi = {qv[2], qv[3]};
+#if OEM_E_QUEUE_SC == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(qp), "v"(lo), "v"(hi) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" ::"v"(qp), "v"(lo), "v"(hi) : "memory");
+#endif
+#elif OEM_E_QUEUE_SC == 3
+#pragma unroll
+    for (int b = 0; b < 4; ++b) qp[b] = qv[b];
+#else
+#pragma unroll
+    for (int b = 0; b < 4; ++b) __builtin_nontemporal_store(qv[b], &qp[b]);
+#endif
 }
 
 template <typename WT>
@@ -638,8 +662,7 @@ __global__ __launch_bounds__(kTileThreadsE, TileShapeE<kRows>::min_waves) void k
                 double qv[kEB];
 #pragma unroll
                 for (int b = 0; b < kEB; ++b) qv[b] = wv * den_l[b * kRows + rrow[k]];
-#pragma unroll
-                for (int b = 0; b < kEB; ++b) __builtin_nontemporal_store(qv[b], &qp[b]);
+                store_queue_piece(qp, qv);
             }
         }
         for (uint32_t i = tx + kRem * kTileThreadsE; i < td.remote_cnt; i += kTileThreadsE) {

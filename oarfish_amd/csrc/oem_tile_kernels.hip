@@ -13,6 +13,7 @@
 // HBM-bound by design (no MFMA: this is sparse gather/scatter).  Algorithmic
 // bytes per pass are SURVEY.md section 8d's nnz*(4+4) + (R+1)*4 + 2*T*8.
 #include <cstdlib>
+#include <vector>
 
 #include "oem_internal.h"
 
@@ -595,6 +596,27 @@ static uint32_t fold_groups(const DeviceTiled &t)
     return n_groups;
 }
 
+// The fold of a pass's queue (k_remote_fold), on `stream`.
+static int launch_remote_fold(oem_store *s, hipStream_t stream, double *cnt, const EmState *state, const BatchState *problems,
+                              uint32_t problem_size, unsigned long long *rd_slots, EmState *rd_state, EmParams rd_p,
+                              uint32_t rd_decide)
+{
+    const DeviceTiled &t = s->tiled;
+    const uint64_t wsz = s->csr.w_is_f64 ? 8 : 4;
+    const uint64_t stream_bytes = (t.n_local + t.n_local / 8) * (wsz + 2) + t.n_remote * (wsz + (t.packed ? 4 : 6));
+    const uint32_t n_groups = fold_groups(t);
+    if (stream_bytes > (96ull << 20)) // (2.5 M reads, 170 MB of streams: already better cached -- see kNTQ)
+        hipLaunchKernelGGL(k_remote_fold<false>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
+                           stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
+                           s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
+    else
+        hipLaunchKernelGGL(k_remote_fold<true>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
+                           stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
+                           s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
+    OEM_HIP(hipGetLastError());
+    return OEM_OK;
+}
+
 int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const EmState *state,
                          const uint32_t *row_w_perm, const BatchState *problems, uint32_t problem_size, bool skip_fold,
                          const DeferredRelDiff *rd)
@@ -652,16 +674,7 @@ int launch_em_pass_tiled(oem_store *s, const double *theta, double *cnt, const E
     const EmParams rd_p = rd ? rd->p : EmParams{0, 0, 0, 0.0};
     const uint32_t rd_decide = rd && rd->prev ? rd->decide : 0u;
     if (t.n_remote > 0 && !skip_fold) { // (the per-cell batch folds and finishes the pass in one kernel)
-        const uint32_t n_groups = fold_groups(t);
-        if (stream_bytes > (96ull << 20)) // (2.5 M reads, 170 MB of streams: already better cached -- see kNTQ)
-            hipLaunchKernelGGL(k_remote_fold<false>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
-                               s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                               s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
-        else
-            hipLaunchKernelGGL(k_remote_fold<true>, dim3(t.n_buckets * n_groups), dim3(kFoldThreads), 0,
-                               s->stream, t.bucket_base, t.queue, t.q_dst, cnt, state, n_groups,
-                               s->csr.n_txps, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide);
-        OEM_HIP(hipGetLastError());
+        OEM_TRY(launch_remote_fold(s, s->stream, cnt, state, problems, problem_size, rd_slots, rd_state, rd_p, rd_decide));
     } else if (rd_decide) { // no fold to carry the decision (a store without remote alignments)
         hipLaunchKernelGGL(k_deferred_decide, dim3(1), dim3(64), 0, s->stream, rd_slots, rd_state, rd_p, rd_decide);
         OEM_HIP(hipGetLastError());
@@ -754,5 +767,64 @@ extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint6
     hipFree(d);
     return rc;
     OEM_API_END("oem_debug_tile_probe")
+}
+// Test hook (scripts/overlap_probe.py): how much of a pass's fold hides under a tile kernel.  out_us[0] = tile kernel
+// alone, [1] = fold alone, [2] = tile + fold on one stream (the pass), [3] = per iteration when fold i runs on a second
+// stream behind tile i (an event) while tile i + 1 runs -- the results are meaningless, the time says what a fold
+// that overlaps the next tiles would cost.  n launches each, HIP events on the store's stream.
+extern "C" int oem_debug_overlap_probe(oem_store *s, uint32_t n, double *out_us)
+{
+    using namespace oem;
+    OEM_API_BEGIN
+    if (!s || !out_us || !n || !s->tiled.present || !s->tiled.n_remote)
+        return fail(OEM_ERR_ARG, "oem_debug_overlap_probe: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    OEM_HIP(hipSetDevice(s->device));
+    const uint32_t T = s->csr.n_txps;
+    OEM_TRY(launch_fill(s, s->theta, (double)s->global_n_reads / (double)T, T));
+    OEM_HIP(hipMemsetAsync(s->cnt, 0, sizeof(double) * T, s->stream));
+    hipStream_t s2 = nullptr;
+    OEM_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t e0, e1, ej;
+    OEM_HIP(hipEventCreate(&e0));
+    OEM_HIP(hipEventCreate(&e1));
+    OEM_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    std::vector<hipEvent_t> ev(n);
+    for (auto &e : ev) OEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const EmParams p0{0, 0, 0, 0.0};
+    auto timed = [&](int mode, double *us) -> int {
+        for (int rep = 0; rep < 2; ++rep) { // (the first round warms)
+            OEM_HIP(hipEventRecord(e0, s->stream));
+            for (uint32_t i = 0; i < n; ++i) {
+                if (mode != 1) OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, nullptr, 0, mode != 2));
+                if (mode == 1) OEM_TRY(launch_remote_fold(s, s->stream, s->cnt, nullptr, nullptr, 0, nullptr, nullptr, p0, 0));
+                if (mode == 3) {
+                    OEM_HIP(hipEventRecord(ev[i], s->stream));
+                    OEM_HIP(hipStreamWaitEvent(s2, ev[i], 0));
+                    OEM_TRY(launch_remote_fold(s, s2, s->cnt, nullptr, nullptr, 0, nullptr, nullptr, p0, 0));
+                }
+            }
+            if (mode == 3) {
+                OEM_HIP(hipEventRecord(ej, s2));
+                OEM_HIP(hipStreamWaitEvent(s->stream, ej, 0));
+            }
+            OEM_HIP(hipEventRecord(e1, s->stream));
+            OEM_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            OEM_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *us = (double)ms * 1e3 / n;
+        }
+        return OEM_OK;
+    };
+    for (int r = 0; r < 50; ++r) OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr)); // settle
+    int rc = OEM_OK;
+    for (int m = 0; m < 4 && rc == OEM_OK; ++m) rc = timed(m == 0 ? 0 : m, &out_us[m]);
+    hipStreamSynchronize(s->stream);
+    hipStreamSynchronize(s2);
+    for (auto &e : ev) hipEventDestroy(e);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ej);
+    hipStreamDestroy(s2);
+    return rc;
+    OEM_API_END("oem_debug_overlap_probe")
 }
 #endif
