@@ -83,54 +83,32 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
     __shared__ unsigned long long cmax[kMaxCellsPerBucket];
     __shared__ uint32_t phase_l[kMaxCellsPerBucket];
     const uint32_t b = live_buckets ? live_buckets[blockIdx.x] : blockIdx.x;
-    // A bucket of a cell has a few entries per thread: the workgroup lives as long as its chain of round trips, and
-    // 9 000 of them pass through 512 slots per pass.  Everything that does not hang on another load is therefore
-    // requested HERE, at once: the queue range, the cells' phases, and the counts and abundances of the closing sweep
-    // (the tile kernel's flush is complete at the kernel boundary and the bucket has no other writer) -- the sweep
-    // used to ask for them behind the fold, a second loaded round trip of a workgroup that lived for four.
-    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
     const uint32_t t0 = b * kBucket;
     uint32_t t1 = t0 + kBucket - 1;
     if (t1 >= n_txps) t1 = n_txps - 1;
     const uint32_t p0 = t0 / T, p1 = t1 / T, n_cells = p1 - p0 + 1;
     const bool small = n_cells <= kMaxCellsPerBucket;
-    // (the first vector load: waiting for it then waits for nothing else)
-    const uint32_t my_phase = small && threadIdx.x < n_cells ? st[p0 + threadIdx.x].phase : 0u;
-    constexpr uint32_t kPerThread = kBucket / kFT;
-    static_assert(kBucket % kFT == 0, "a thread sweeps kBucket / kFT window entries");
-    double cv[kPerThread], pv[kPerThread];
-#pragma unroll
-    for (uint32_t k = 0; k < kPerThread; ++k) {
-        const uint32_t i = threadIdx.x + k * kFT, t = t0 + i < n_txps ? t0 + i : n_txps - 1;
-        cv[k] = cnt[t];
-        pv[k] = theta[t];
-    }
     bool live = false;
     for (uint32_t p = p0; p <= p1; ++p) live = live || st[p].phase != kPhaseFinished;
     if (!live) return;
+    if (small && threadIdx.x < n_cells) {
+        cmax[threadIdx.x] = 0ull;
+        phase_l[threadIdx.x] = st[p0 + threadIdx.x].phase;
+    }
+    for (uint32_t i = threadIdx.x; i < kBucket; i += kFT) acc[i] = 0.0;
+    __syncthreads();
+    const uint32_t q0 = bucket_base[b], q1 = bucket_base[b + 1];
     // four loads in flight per thread (a cell's bucket has a few entries per thread: one round trip instead of one
-    // per entry); entries past the range are clamped to its last one and skipped at the point of use.  The first
-    // trip -- for a cell's bucket the only one -- is in flight while the window is cleared.
-    double v[4];
-    uint32_t d[4];
-    auto load4 = [&](uint32_t o) {
+    // per entry); entries past the range are clamped to its last one and skipped at the point of use
+    for (uint32_t o = q0 + threadIdx.x; o < q1; o += 4 * kFT) {
+        double v[4];
+        uint32_t d[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t oo = o + k * kFT, oc = oo < q1 ? oo : q1 - 1;
             v[k] = __builtin_nontemporal_load(&queue[oc]); // (read once: the abundances and counts keep the caches)
             d[k] = __builtin_nontemporal_load(&q_dst[oc]);
         }
-    };
-    if (q0 < q1) load4(q0 + threadIdx.x); // (workgroup-uniform)
-    if (small && threadIdx.x < n_cells) {
-        cmax[threadIdx.x] = 0ull;
-        phase_l[threadIdx.x] = my_phase;
-    }
-    for (uint32_t i = threadIdx.x; i < kBucket; i += kFT) acc[i] = 0.0;
-    __syncthreads();
-    for (uint32_t ob = q0; ob < q1; ob += 4 * kFT) { // (workgroup-uniform trips)
-        const uint32_t o = ob + threadIdx.x;
-        if (ob != q0) load4(o);
         const bool rep = keys_repeat(d[0]); // hot destinations: runs of equal ones summed on the vector ALU first (oem_lane_runs.h)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -140,6 +118,16 @@ __global__ __launch_bounds__(kFT) void k_multi_fold_reldiff(const uint32_t *__re
         }
     }
     __syncthreads();
+    // the counts and abundances of this thread's window entries: requested together, then swept
+    constexpr uint32_t kPerThread = kBucket / kFT;
+    static_assert(kBucket % kFT == 0, "a thread sweeps kBucket / kFT window entries");
+    double cv[kPerThread], pv[kPerThread];
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        const uint32_t i = threadIdx.x + k * kFT, t = t0 + i < n_txps ? t0 + i : n_txps - 1;
+        cv[k] = cnt[t];
+        pv[k] = theta[t];
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
         const uint32_t i = threadIdx.x + k * kFT;
