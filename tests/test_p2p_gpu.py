@@ -32,7 +32,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,mode,shape", [(2, "full", 0), (3, "small", 2), (4, "full", 2), (2, "small", 2), (3, "full", 1), (4, "small", 0)])
+@pytest.mark.parametrize("world,mode,shape", [(2, "full", 0), (3, "small", 2), (4, "full", 2), (2, "small", 2), (3, "full", 1), (4, "small", 0),
+                                              (8, "full", 0), (8, "small", 2), (6, "full", 1)])
 def test_row_sharded_loop_over_p2p_with_processes_sharing_one_gpu(world, mode, shape, tmp_path):
     """shape 0: what the library picks (one-shot for this store's short vectors); 1 / 2: one-shot / two-phase forced."""
     out = tmp_path / "p2p.json"
