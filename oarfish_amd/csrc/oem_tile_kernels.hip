@@ -51,7 +51,8 @@ namespace oem {
 
 namespace {
 
-constexpr int kFoldThreads = 1024;
+constexpr int kFoldThreadsDefault = 1024;
+constexpr int kFoldThreads = kFoldThreadsDefault; // (the launchers' block size; the kernel takes it as a template argument: the overlap probe folds with 256)
 constexpr uint32_t kFoldEntriesPerGroup = 2 * kBucket; // queue entries that repay a fold workgroup's window clear + flush
 
 #ifdef OEM_TESTING
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_deferred_sweep(double *__rest
 // Infinity Cache with room to spare (C2: 1 M reads) gains 2.7 % of its pass -- the entries are read once and theta and the
 // counts keep the L2 -- while at C3 the fold finds the entries the tile kernel has just written in the caches, and
 // reading past them costs 2.8 % (2.5 M reads: 1.6 %; 1.25 M: the same either way).
-template <bool kNTQ>
+template <bool kNTQ, int kFoldThreads = oem::kFoldThreadsDefault>
 __global__ __launch_bounds__(kFoldThreads) void k_remote_fold(
     const uint32_t *__restrict__ bucket_base, const double *__restrict__ queue,
     const uint16_t *__restrict__ q_dst, double *__restrict__ cnt, const EmState *state,
@@ -771,7 +772,9 @@ extern "C" int oem_debug_tile_probe(oem_store *s, unsigned long long *out, uint6
 // Test hook (scripts/overlap_probe.py): how much of a pass's fold hides under a tile kernel.  out_us[0] = tile kernel
 // alone, [1] = fold alone, [2] = tile + fold on one stream (the pass), [3] = per iteration when fold i runs on a second
 // stream behind tile i (an event) while tile i + 1 runs -- the results are meaningless, the time says what a fold
-// that overlaps the next tiles would cost.  n launches each, HIP events on the store's stream.
+// that overlaps the next tiles would cost; [4] = the fold in 256-thread workgroups alone, [5] = that fold on the second
+// stream under the next tile kernel, [6] = tile + that fold on one stream.  n launches each, HIP events on the
+// store's stream; out_us has 7 entries.
 extern "C" int oem_debug_overlap_probe(oem_store *s, uint32_t n, double *out_us)
 {
     using namespace oem;
@@ -792,19 +795,34 @@ extern "C" int oem_debug_overlap_probe(oem_store *s, uint32_t n, double *out_us)
     std::vector<hipEvent_t> ev(n);
     for (auto &e : ev) OEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const EmParams p0{0, 0, 0, 0.0};
+    // the same fold in workgroups of the tile kernel's shape (256 threads; four times the groups): a 1024-thread,
+    // 32 KiB workgroup is not placed on a CU while 4-wavefront tile workgroups are pending -- the dispatcher refills
+    // the slots a finished tile leaves with the next tile -- so the fat fold only ever ran in the tile kernel's tail
+    auto thin_fold = [&](hipStream_t st) -> int {
+        const DeviceTiled &t = s->tiled;
+        const uint32_t n_groups = fold_groups(t) * 4;
+        hipLaunchKernelGGL((k_remote_fold<false, 256>), dim3(t.n_buckets * n_groups), dim3(256), 0, st, t.bucket_base, t.queue,
+                           t.q_dst, s->cnt, (const EmState *)nullptr, n_groups, s->csr.n_txps, (const BatchState *)nullptr, 0u,
+                           (unsigned long long *)nullptr, (EmState *)nullptr, p0, 0u);
+        OEM_HIP(hipGetLastError());
+        return OEM_OK;
+    };
     auto timed = [&](int mode, double *us) -> int {
         for (int rep = 0; rep < 2; ++rep) { // (the first round warms)
             OEM_HIP(hipEventRecord(e0, s->stream));
             for (uint32_t i = 0; i < n; ++i) {
-                if (mode != 1) OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, nullptr, 0, mode != 2));
+                if (mode != 1 && mode != 4) OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr, nullptr, 0, mode != 2));
                 if (mode == 1) OEM_TRY(launch_remote_fold(s, s->stream, s->cnt, nullptr, nullptr, 0, nullptr, nullptr, p0, 0));
-                if (mode == 3) {
+                if (mode == 4) OEM_TRY(thin_fold(s->stream));
+                if (mode == 6) OEM_TRY(thin_fold(s->stream)); // (tile + thin fold on one stream)
+                if (mode == 3 || mode == 5) {
                     OEM_HIP(hipEventRecord(ev[i], s->stream));
                     OEM_HIP(hipStreamWaitEvent(s2, ev[i], 0));
-                    OEM_TRY(launch_remote_fold(s, s2, s->cnt, nullptr, nullptr, 0, nullptr, nullptr, p0, 0));
+                    if (mode == 3) OEM_TRY(launch_remote_fold(s, s2, s->cnt, nullptr, nullptr, 0, nullptr, nullptr, p0, 0));
+                    else OEM_TRY(thin_fold(s2));
                 }
             }
-            if (mode == 3) {
+            if (mode == 3 || mode == 5) {
                 OEM_HIP(hipEventRecord(ej, s2));
                 OEM_HIP(hipStreamWaitEvent(s->stream, ej, 0));
             }
@@ -818,7 +836,7 @@ extern "C" int oem_debug_overlap_probe(oem_store *s, uint32_t n, double *out_us)
     };
     for (int r = 0; r < 50; ++r) OEM_TRY(launch_em_pass_tiled(s, s->theta, s->cnt, nullptr, nullptr)); // settle
     int rc = OEM_OK;
-    for (int m = 0; m < 4 && rc == OEM_OK; ++m) rc = timed(m == 0 ? 0 : m, &out_us[m]);
+    for (int m = 0; m < 7 && rc == OEM_OK; ++m) rc = timed(m, &out_us[m]);
     hipStreamSynchronize(s->stream);
     hipStreamSynchronize(s2);
     for (auto &e : ev) hipEventDestroy(e);

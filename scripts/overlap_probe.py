@@ -21,8 +21,10 @@ with _lib.testing():
     st = synth.make_config(wl)
     with DeviceStore(st.row_ptr, st.tid, st.as_prob, None, st.n_txps) as d:
         for rnd in range(3):
-            out = np.zeros(4)
+            out = np.zeros(7)
             _lib.check(L.oem_debug_overlap_probe(d.handle, n, out.ctypes.data))
             print(f"{wl} x{n}: tile {out[0]:.1f} us, fold {out[1]:.1f} us, pass (one stream) {out[2]:.1f} us, "
                   f"fold on a second stream under the next tile kernel {out[3]:.1f} us per iteration "
-                  f"(hidden: {out[2] - out[3]:.1f} of {out[1]:.1f} us)")
+                  f"(hidden: {out[2] - out[3]:.1f} of {out[1]:.1f} us); the fold in 256-thread workgroups: alone {out[4]:.1f} us, "
+                  f"tile + it on one stream {out[6]:.1f} us, on the second stream {out[5]:.1f} us per iteration "
+                  f"(hidden: {out[6] - out[5]:.1f} of {out[4]:.1f} us)")
