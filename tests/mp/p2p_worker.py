@@ -36,7 +36,10 @@ res = {}
 err = None
 try:
     with DeviceStore(sh.row_ptr, sh.tid, sh.as_prob, None, T, device=0) as d:
-        comm = odist.create_comm(rank, world, 0, backend="p2p", p2p_capacity=T if small_capacity else 2 * T * 4)
+        # (many processes time-share the one device: a rank's waiting kernel can sit in front of the kernels it waits
+        # for until the hardware scheduler's time slice ends -- a longer bound than the library's 8 s for the large worlds)
+        comm = odist.create_comm(rank, world, 0, backend="p2p", p2p_capacity=T if small_capacity else 2 * T * 4,
+                                 p2p_timeout_ms=60_000 if world > 4 else 0)
         try:
             comm.set_p2p_shape(shape)
             d.attach_comm(comm.handle, st.n_reads, sh.row_begin)
